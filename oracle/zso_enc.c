@@ -1,0 +1,1153 @@
+/*
+ * oracle/zso_enc.c — CPU oracle: zstd frame encoder, levels 1-2 ("fast" strategy) plus the
+ * strategy-independent entropy stage.  TEST INFRASTRUCTURE ONLY (see zso_common.h).
+ * Restates, in plain C, the compress path of the reference:
+ *
+ *   level -> cParams          U/ZstdCompress.cs:7891-7927, 2023-2094 ; U/Clevels.cs:10,243,476,709
+ *   frame header / epilogue   U/ZstdCompress.cs:4817-4929, 5598-5656
+ *   block loop                U/ZstdCompress.cs:4690-4815, 4528-4582, 3432-3530
+ *   fast match finder         U/ZstdFast.cs:96-288 ; hashes U/ZstdCompressInternal.cs:340-434
+ *   seqStore / codes          U/ZstdCompressInternal.cs:20-38, 204-246 ; U/ZstdCompress.cs:3069-3098
+ *   literals section          U/ZstdCompressLiterals.cs:8-185
+ *   Huffman                   U/Hist.cs ; U/HufCompress.cs:40-235, 377-823, 989-1355, 1360-1543
+ *   sequences section         U/ZstdCompress.cs:3127-3392 ; U/ZstdCompressSequences.cs:400-704
+ *   FSE                       U/FseCompress.cs:13-360, 384-720 ; U/Fse.cs:10-57 ; U/Bitstream.cs:15-160
+ *
+ * The goal is byte-for-byte the reference's output for these levels (dictionary-less, single thread);
+ * workspace carving, SIMD/unrolling and other CPU mechanics that do not change bytes are not restated.
+ */
+#include "zso_enc.h"
+#include <stdlib.h>
+
+/* ------------------------------------------------------------------ */
+/*  parameters                                                         */
+/* ------------------------------------------------------------------ */
+/* rows 0..5 of the four size tiers, U/Clevels.cs:10 (>256K), :243 (<=256K), :476 (<=128K), :709 (<=16K) */
+static const zso_cparams ZSO_levels[4][6] = {
+  { {19,12,13,1,6,1,ZSO_fast}, {19,13,14,1,7,0,ZSO_fast}, {20,15,16,1,6,0,ZSO_fast},
+    {21,16,17,1,5,0,ZSO_dfast}, {21,18,18,1,5,0,ZSO_dfast}, {21,18,19,3,5,2,ZSO_greedy} },
+  { {18,12,13,1,5,1,ZSO_fast}, {18,13,14,1,6,0,ZSO_fast}, {18,14,14,1,5,0,ZSO_dfast},
+    {18,16,16,1,4,0,ZSO_dfast}, {18,16,17,3,5,2,ZSO_greedy}, {18,17,18,5,5,2,ZSO_greedy} },
+  { {17,12,12,1,5,1,ZSO_fast}, {17,12,13,1,6,0,ZSO_fast}, {17,13,15,1,5,0,ZSO_fast},
+    {17,15,16,2,5,0,ZSO_dfast}, {17,17,17,2,4,0,ZSO_dfast}, {17,16,17,3,4,2,ZSO_greedy} },
+  { {14,12,13,1,5,1,ZSO_fast}, {14,14,15,1,5,0,ZSO_fast}, {14,14,15,1,4,0,ZSO_fast},
+    {14,14,15,2,4,0,ZSO_dfast}, {14,14,14,4,4,2,ZSO_greedy}, {14,14,14,3,4,4,ZSO_lazy} },
+};
+
+zso_cparams zso_getCParams(int level, u64 srcSize)
+{
+    u32 const tableID = (srcSize <= 256 * 1024) + (srcSize <= 128 * 1024) + (srcSize <= 16 * 1024);
+    int row = level == 0 ? 3 : level < 0 ? 0 : level > 5 ? 5 : level;   /* oracle covers rows 0..5 only */
+    zso_cparams cp = ZSO_levels[tableID][row];
+    if (level < 0) cp.targetLength = (u32)(-level);
+    /* ZSTD_adjustCParams_internal, no dictionary */
+    if (srcSize < ((u64)1 << 30)) {
+        u32 const tSize = (u32)srcSize;
+        u32 const srcLog = (tSize < 64) ? 6 : zso_highbit32(tSize - 1) + 1;
+        if (cp.windowLog > srcLog) cp.windowLog = srcLog;
+    }
+    {   u32 const cycleLog = cp.chainLog;   /* ZSTD_cycleLog: chainLog - (strategy >= btlazy2) */
+        if (cp.hashLog > cp.windowLog + 1) cp.hashLog = cp.windowLog + 1;
+        if (cycleLog > cp.windowLog) cp.chainLog -= (cycleLog - cp.windowLog);
+    }
+    if (cp.windowLog < 10) cp.windowLog = 10;
+    return cp;
+}
+
+/* ZSTD_compressBound, U/ZstdCompress.cs:19-22 */
+size_t zso_compressBound(size_t n) { return n + (n >> 8) + (n < (128 << 10) ? ((128 << 10) - n) >> 11 : 0); }
+
+/* ------------------------------------------------------------------ */
+/*  forward bit writer  (BIT_CStream_t)                                */
+/* ------------------------------------------------------------------ */
+typedef struct { u8* start; u8* ptr; u8* end; u64 acc; u32 nbits; int overflow; } zso_bitc;
+
+static size_t bitc_init(zso_bitc* b, void* dst, size_t cap)
+{
+    if (cap <= 8) return ZSO_ERR(dstSize_tooSmall);
+    b->start = b->ptr = (u8*)dst; b->end = b->start + cap - 8;   /* the reference keeps one container of slack */
+    b->acc = 0; b->nbits = 0; b->overflow = 0;
+    return 0;
+}
+static inline void bitc_add(zso_bitc* b, u64 value, u32 n)
+{
+    if (n) value &= (((u64)1 << n) - 1); else value = 0;
+    b->acc |= value << b->nbits; b->nbits += n;
+    while (b->nbits >= 8) {
+        if (b->ptr < b->end) *b->ptr++ = (u8)b->acc; else b->overflow = 1;
+        b->acc >>= 8; b->nbits -= 8;
+    }
+}
+static size_t bitc_close(zso_bitc* b)
+{
+    bitc_add(b, 1, 1);                                  /* end mark */
+    if (b->overflow || b->ptr >= b->end) return 0;
+    if (b->nbits) { *b->ptr = (u8)b->acc; return (size_t)(b->ptr - b->start) + 1; }
+    return (size_t)(b->ptr - b->start);
+}
+
+/* ------------------------------------------------------------------ */
+/*  histogram  (U/Hist.cs)                                             */
+/* ------------------------------------------------------------------ */
+static u32 zso_hist(u32* count, u32* maxSVPtr, const u8* src, size_t n)
+{
+    u32 maxSV = *maxSVPtr, s, largest = 0; size_t i;
+    memset(count, 0, (maxSV + 1) * sizeof(u32));
+    if (!n) { *maxSVPtr = 0; return 0; }
+    for (i = 0; i < n; i++) count[src[i]]++;
+    while (!count[maxSV]) maxSV--;
+    *maxSVPtr = maxSV;
+    for (s = 0; s <= maxSV; s++) if (count[s] > largest) largest = count[s];
+    return largest;
+}
+
+/* ------------------------------------------------------------------ */
+/*  FSE compression tables                                             */
+/* ------------------------------------------------------------------ */
+typedef struct { int deltaFindState; u32 deltaNbBits; } zso_symTT;
+typedef struct { u32 tableLog; u32 maxSV; u16 stateTable[512]; zso_symTT tt[256]; } zso_fse_ct;
+
+static u32 zso_fse_minTableLog(size_t srcSize, u32 maxSV)
+{
+    u32 const a = zso_highbit32((u32)srcSize) + 1, b = zso_highbit32(maxSV) + 2;
+    return a < b ? a : b;
+}
+/* FSE_optimalTableLog_internal, U/FseCompress.cs:397-430 */
+static u32 zso_fse_optimalTableLog(u32 maxTableLog, size_t srcSize, u32 maxSV, u32 minus)
+{
+    u32 const maxBitsSrc = zso_highbit32((u32)(srcSize - 1)) - minus;
+    u32 tableLog = maxTableLog, minBits = zso_fse_minTableLog(srcSize, maxSV);
+    if (tableLog == 0) tableLog = 11;
+    if (maxBitsSrc < tableLog) tableLog = maxBitsSrc;
+    if (minBits > tableLog) tableLog = minBits;
+    if (tableLog < 5) tableLog = 5;
+    if (tableLog > 12) tableLog = 12;
+    return tableLog;
+}
+
+/* FSE_normalizeM2, U/FseCompress.cs:443-561 */
+static size_t zso_fse_normalizeM2(s16* norm, u32 tableLog, const u32* count, size_t total, u32 maxSV, s16 lowProbCount)
+{
+    s16 const NOT_YET = -2;
+    u32 s, distributed = 0, ToDistribute;
+    u32 const lowThreshold = (u32)(total >> tableLog);
+    u32 lowOne = (u32)((total * 3) >> (tableLog + 1));
+    for (s = 0; s <= maxSV; s++) {
+        if (count[s] == 0) { norm[s] = 0; continue; }
+        if (count[s] <= lowThreshold) { norm[s] = lowProbCount; distributed++; total -= count[s]; continue; }
+        if (count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; continue; }
+        norm[s] = NOT_YET;
+    }
+    ToDistribute = (1u << tableLog) - distributed;
+    if (ToDistribute == 0) return 0;
+    if ((total / ToDistribute) > lowOne) {
+        lowOne = (u32)((total * 3) / (ToDistribute * 2));
+        for (s = 0; s <= maxSV; s++)
+            if (norm[s] == NOT_YET && count[s] <= lowOne) { norm[s] = 1; distributed++; total -= count[s]; }
+        ToDistribute = (1u << tableLog) - distributed;
+    }
+    if (distributed == maxSV + 1) {
+        u32 maxV = 0, maxC = 0;
+        for (s = 0; s <= maxSV; s++) if (count[s] > maxC) { maxV = s; maxC = count[s]; }
+        norm[maxV] += (s16)ToDistribute;
+        return 0;
+    }
+    if (total == 0) {
+        for (s = 0; ToDistribute > 0; s = (s + 1) % (maxSV + 1)) if (norm[s] > 0) { ToDistribute--; norm[s]++; }
+        return 0;
+    }
+    {   u64 const vStepLog = 62 - tableLog, mid = ((u64)1 << (vStepLog - 1)) - 1;
+        u64 const rStep = ((((u64)1 << vStepLog) * ToDistribute) + mid) / (u32)total;
+        u64 tmpTotal = mid;
+        for (s = 0; s <= maxSV; s++) {
+            if (norm[s] == NOT_YET) {
+                u64 const end = tmpTotal + (count[s] * rStep);
+                u32 const sStart = (u32)(tmpTotal >> vStepLog), sEnd = (u32)(end >> vStepLog), weight = sEnd - sStart;
+                if (weight < 1) return ZSO_ERR(GENERIC);
+                norm[s] = (s16)weight; tmpTotal = end;
+            }
+        }
+    }
+    return 0;
+}
+
+/* FSE_normalizeCount, U/FseCompress.cs:574-665 ; rtbTable U/Arrays.cs:8 */
+static size_t zso_fse_normalizeCount(s16* norm, u32 tableLog, const u32* count, size_t total, u32 maxSV, u32 useLowProbCount)
+{
+    static const u32 rtb[8] = { 0, 473195, 504333, 520860, 550000, 700000, 750000, 830000 };
+    if (tableLog == 0) tableLog = 11;
+    if (tableLog < 5) return ZSO_ERR(GENERIC);
+    if (tableLog > 12) return ZSO_ERR(tableLog_tooLarge);
+    if (tableLog < zso_fse_minTableLog(total, maxSV)) return ZSO_ERR(GENERIC);
+    {   s16 const lowProbCount = useLowProbCount ? -1 : 1;
+        u64 const scale = 62 - tableLog, step = ((u64)1 << 62) / (u32)total, vStep = (u64)1 << (scale - 20);
+        int stillToDistribute = 1 << tableLog;
+        u32 s, largest = 0; s16 largestP = 0;
+        u32 const lowThreshold = (u32)(total >> tableLog);
+        for (s = 0; s <= maxSV; s++) {
+            if (count[s] == total) return 0;                       /* rle special case */
+            if (count[s] == 0) { norm[s] = 0; continue; }
+            if (count[s] <= lowThreshold) { norm[s] = lowProbCount; stillToDistribute--; }
+            else {
+                s16 proba = (s16)((count[s] * step) >> scale);
+                if (proba < 8) {
+                    u64 const restToBeat = vStep * rtb[proba];
+                    proba += (count[s] * step) - ((u64)proba << scale) > restToBeat;
+                }
+                if (proba > largestP) { largestP = proba; largest = s; }
+                norm[s] = proba; stillToDistribute -= proba;
+            }
+        }
+        if (-stillToDistribute >= (norm[largest] >> 1)) {
+            size_t const e = zso_fse_normalizeM2(norm, tableLog, count, total, maxSV, lowProbCount);
+            if (zso_isError(e)) return e;
+        } else norm[largest] += (s16)stillToDistribute;
+    }
+    return tableLog;
+}
+
+/* FSE_writeNCount_generic, U/FseCompress.cs:203-336 (capacity handling reduced to a bound check) */
+static size_t zso_fse_writeNCount(void* header, size_t cap, const s16* norm, u32 maxSV, u32 tableLog)
+{
+    u8 tmp[512]; u8* out = tmp;
+    int nbBits = (int)tableLog + 1, remaining = (1 << tableLog) + 1, threshold = 1 << tableLog;
+    u32 bitStream = 0; int bitCount = 0; u32 symbol = 0; u32 const alphabetSize = maxSV + 1; int previousIs0 = 0;
+    if (tableLog > 12) return ZSO_ERR(tableLog_tooLarge);
+    if (tableLog < 5) return ZSO_ERR(GENERIC);
+    bitStream += (tableLog - 5) << bitCount; bitCount += 4;
+    while (symbol < alphabetSize && remaining > 1) {
+        if (previousIs0) {
+            u32 start = symbol;
+            while (symbol < alphabetSize && !norm[symbol]) symbol++;
+            if (symbol == alphabetSize) break;
+            while (symbol >= start + 24) {
+                start += 24; bitStream += 0xFFFFu << bitCount;
+                out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16;
+            }
+            while (symbol >= start + 3) { start += 3; bitStream += 3u << bitCount; bitCount += 2; }
+            bitStream += (symbol - start) << bitCount; bitCount += 2;
+            if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+        }
+        {   int count = norm[symbol++];
+            int const max = (2 * threshold - 1) - remaining;
+            remaining -= count < 0 ? -count : count;
+            count++;
+            if (count >= threshold) count += max;
+            bitStream += (u32)count << bitCount;
+            bitCount += nbBits; bitCount -= (count < max);
+            previousIs0 = (count == 1);
+            if (remaining < 1) return ZSO_ERR(GENERIC);
+            while (remaining < threshold) { nbBits--; threshold >>= 1; }
+        }
+        if (bitCount > 16) { out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += 2; bitStream >>= 16; bitCount -= 16; }
+    }
+    if (remaining != 1) return ZSO_ERR(GENERIC);
+    out[0] = (u8)bitStream; out[1] = (u8)(bitStream >> 8); out += (bitCount + 7) / 8;
+    {   size_t const n = (size_t)(out - tmp);
+        if (n > cap) return ZSO_ERR(dstSize_tooSmall);
+        memcpy(header, tmp, n);
+        return n;
+    }
+}
+
+/* FSE_buildCTable_wksp, U/FseCompress.cs:13-191 */
+static size_t zso_fse_buildCTable(zso_fse_ct* ct, const s16* norm, u32 maxSV, u32 tableLog)
+{
+    u32 const tableSize = 1u << tableLog, tableMask = tableSize - 1;
+    u32 const step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    u16 cumul[258]; u8 tableSymbol[4096];
+    u32 highThreshold = tableSize - 1, u;
+    if (tableLog > 9 && maxSV > 52) { if (tableLog > 12) return ZSO_ERR(tableLog_tooLarge); }
+    ct->tableLog = tableLog; ct->maxSV = maxSV;
+    cumul[0] = 0;
+    for (u = 1; u <= maxSV + 1; u++) {
+        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (u8)(u - 1); }
+        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
+    }
+    cumul[maxSV + 1] = (u16)(tableSize + 1);
+    {   u32 position = 0, symbol;     /* the reference's "no low-prob" fast path lays out the same table */
+        for (symbol = 0; symbol <= maxSV; symbol++) {
+            int n;
+            for (n = 0; n < norm[symbol]; n++) {
+                tableSymbol[position] = (u8)symbol;
+                position = (position + step) & tableMask;
+                while (position > highThreshold) position = (position + step) & tableMask;
+            }
+        }
+        if (position != 0) return ZSO_ERR(GENERIC);
+    }
+    for (u = 0; u < tableSize; u++) { u8 const s = tableSymbol[u]; ct->stateTable[cumul[s]++] = (u16)(tableSize + u); }
+    {   u32 total = 0, s;
+        for (s = 0; s <= maxSV; s++) {
+            switch (norm[s]) {
+            case 0: ct->tt[s].deltaNbBits = ((tableLog + 1) << 16) - (1u << tableLog); ct->tt[s].deltaFindState = 0; break;
+            case -1: case 1:
+                ct->tt[s].deltaNbBits = (tableLog << 16) - (1u << tableLog);
+                ct->tt[s].deltaFindState = (int)(total - 1); total++; break;
+            default: {
+                u32 const maxBitsOut = tableLog - zso_highbit32((u32)norm[s] - 1);
+                u32 const minStatePlus = (u32)norm[s] << maxBitsOut;
+                ct->tt[s].deltaNbBits = (maxBitsOut << 16) - minStatePlus;
+                ct->tt[s].deltaFindState = (int)(total - (u32)norm[s]);
+                total += (u32)norm[s]; }
+            }
+        }
+    }
+    return 0;
+}
+/* FSE_buildCTable_rle, U/FseCompress.cs:706-720 */
+static void zso_fse_buildCTable_rle(zso_fse_ct* ct, u8 symbol)
+{
+    ct->tableLog = 0; ct->maxSV = symbol; ct->stateTable[0] = 0; ct->stateTable[1] = 0;
+    ct->tt[symbol].deltaNbBits = 0; ct->tt[symbol].deltaFindState = 0;
+}
+
+/* FSE_CState_t ops, U/Fse.cs:10-57 */
+typedef struct { ptrdiff_t value; const zso_fse_ct* ct; } zso_cstate;
+static void cstate_init2(zso_cstate* st, const zso_fse_ct* ct, u32 symbol)
+{
+    zso_symTT const tt = ct->tt[symbol];
+    u32 const nbBitsOut = (tt.deltaNbBits + (1 << 15)) >> 16;
+    st->ct = ct;
+    st->value = (ptrdiff_t)((nbBitsOut << 16) - tt.deltaNbBits);
+    st->value = ct->stateTable[(st->value >> nbBitsOut) + tt.deltaFindState];
+}
+static inline void cstate_encode(zso_bitc* b, zso_cstate* st, u32 symbol)
+{
+    zso_symTT const tt = st->ct->tt[symbol];
+    u32 const nbBitsOut = (u32)(((size_t)st->value + tt.deltaNbBits) >> 16);
+    bitc_add(b, (u64)st->value, nbBitsOut);
+    st->value = st->ct->stateTable[(st->value >> nbBitsOut) + tt.deltaFindState];
+}
+static inline void cstate_flush(zso_bitc* b, const zso_cstate* st) { bitc_add(b, (u64)st->value, st->ct->tableLog); }
+
+/* FSE_compress_usingCTable_generic, U/FseCompress.cs:722-820: symbol i goes to state (i & 1), last symbol first */
+static size_t zso_fse_compress(void* dst, size_t cap, const u8* src, size_t n, const zso_fse_ct* ct)
+{
+    zso_bitc b; zso_cstate st[2]; size_t i;
+    if (n <= 2) return 0;
+    if (zso_isError(bitc_init(&b, dst, cap))) return 0;
+    cstate_init2(&st[(n - 1) & 1], ct, src[n - 1]);
+    cstate_init2(&st[(n - 2) & 1], ct, src[n - 2]);
+    for (i = n - 2; i-- > 0; ) cstate_encode(&b, &st[i & 1], src[i]);
+    cstate_flush(&b, &st[1]);       /* CState2 first, then CState1 */
+    cstate_flush(&b, &st[0]);
+    return bitc_close(&b);
+}
+
+/* ------------------------------------------------------------------ */
+/*  Huffman                                                            */
+/* ------------------------------------------------------------------ */
+typedef struct { u32 count; u16 parent; u8 byte; u8 nbBits; } zso_node;
+typedef struct { u8 nbBits[256]; u16 val[256]; u32 tableLog; u32 maxSV; int valid; } zso_huf_ct;   /* valid = a table exists */
+enum { HUF_repeat_none = 0, HUF_repeat_check = 1, HUF_repeat_valid = 2 };
+
+/* HUF_sort helpers, U/HufCompress.cs:520-680 */
+static u32 huf_getIndex(u32 count) { return count < 165 ? count : zso_highbit32(count) + 158; }
+static void huf_insertionSort(zso_node* a, int low, int high)
+{
+    int i, size = high - low + 1; a += low;
+    for (i = 1; i < size; i++) {
+        zso_node const key = a[i]; int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = key;
+    }
+}
+static int huf_partition(zso_node* a, int low, int high)
+{
+    u32 const pivot = a[high].count; int i = low - 1, j;
+    for (j = low; j < high; j++) if (a[j].count > pivot) { zso_node t; i++; t = a[i]; a[i] = a[j]; a[j] = t; }
+    { zso_node t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
+    return i + 1;
+}
+static void huf_quickSort(zso_node* a, int low, int high)
+{
+    if (high - low < 8) { huf_insertionSort(a, low, high); return; }
+    while (low < high) {
+        int const idx = huf_partition(a, low, high);
+        if (idx - low < high - idx) { huf_quickSort(a, low, idx - 1); low = idx + 1; }
+        else { huf_quickSort(a, idx + 1, high); high = idx - 1; }
+    }
+}
+static void huf_sort(zso_node* huffNode, const u32* count, u32 maxSV)
+{
+    struct { u16 base, curr; } rp[192];
+    u32 n; u32 const maxSV1 = maxSV + 1;
+    memset(rp, 0, sizeof rp);
+    for (n = 0; n < maxSV1; n++) rp[huf_getIndex(count[n])].base++;
+    for (n = 191; n > 0; n--) { rp[n - 1].base += rp[n].base; rp[n - 1].curr = rp[n - 1].base; }
+    for (n = 0; n < maxSV1; n++) {
+        u32 const c = count[n], r = huf_getIndex(c) + 1, pos = rp[r].curr++;
+        huffNode[pos].count = c; huffNode[pos].byte = (u8)n;
+    }
+    for (n = 165; n < 191; n++) {
+        u32 const bucketSize = rp[n].curr - rp[n].base, bucketStart = rp[n].base;
+        if (bucketSize > 1) huf_quickSort(huffNode + bucketStart, 0, (int)bucketSize - 1);
+    }
+}
+/* HUF_buildTree, U/HufCompress.cs:689-738 */
+static int huf_buildTree(zso_node* huffNode, u32 maxSV)
+{
+    zso_node* const huffNode0 = huffNode - 1;
+    int nonNullRank = (int)maxSV, lowS, lowN, nodeNb = 256, n, nodeRoot;
+    while (huffNode[nonNullRank].count == 0) nonNullRank--;
+    lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
+    huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
+    huffNode[lowS].parent = huffNode[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
+    huffNode0[0].count = 1u << 31;     /* sentinel at huffNode[-1] */
+    while (nodeNb <= nodeRoot) {
+        int const n1 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        int const n2 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        huffNode[nodeNb].count = huffNode[n1].count + huffNode[n2].count;
+        huffNode[n1].parent = huffNode[n2].parent = (u16)nodeNb;
+        nodeNb++;
+    }
+    huffNode[nodeRoot].nbBits = 0;
+    for (n = nodeRoot - 1; n >= 256; n--) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    for (n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    return nonNullRank;
+}
+/* HUF_setMaxHeight, U/HufCompress.cs:377-514 */
+static u32 huf_setMaxHeight(zso_node* huffNode, u32 lastNonNull, u32 maxNbBits)
+{
+    u32 const largestBits = huffNode[lastNonNull].nbBits;
+    if (largestBits <= maxNbBits) return largestBits;
+    {   int totalCost = 0; u32 const baseCost = 1u << (largestBits - maxNbBits); int n = (int)lastNonNull;
+        while (huffNode[n].nbBits > maxNbBits) {
+            totalCost += (int)(baseCost - (1u << (largestBits - huffNode[n].nbBits)));
+            huffNode[n].nbBits = (u8)maxNbBits; n--;
+        }
+        while (huffNode[n].nbBits == maxNbBits) --n;
+        totalCost >>= (largestBits - maxNbBits);
+        {   u32 const noSymbol = 0xF0F0F0F0; u32 rankLast[14]; int pos; u32 currentNbBits = maxNbBits;
+            for (pos = 0; pos < 14; pos++) rankLast[pos] = noSymbol;
+            for (pos = n; pos >= 0; pos--) {
+                if (huffNode[pos].nbBits >= currentNbBits) continue;
+                currentNbBits = huffNode[pos].nbBits;
+                rankLast[maxNbBits - currentNbBits] = (u32)pos;
+            }
+            while (totalCost > 0) {
+                u32 nBitsToDecrease = zso_highbit32((u32)totalCost) + 1;
+                for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+                    u32 const highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
+                    if (highPos == noSymbol) continue;
+                    if (lowPos == noSymbol) break;
+                    {   u32 const highTotal = huffNode[highPos].count, lowTotal = 2 * huffNode[lowPos].count;
+                        if (highTotal <= lowTotal) break;
+                    }
+                }
+                while (nBitsToDecrease <= 12 && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+                totalCost -= 1 << (nBitsToDecrease - 1);
+                huffNode[rankLast[nBitsToDecrease]].nbBits++;
+                if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+                if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+                else {
+                    rankLast[nBitsToDecrease]--;
+                    if (huffNode[rankLast[nBitsToDecrease]].nbBits != maxNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+                }
+            }
+            while (totalCost < 0) {
+                if (rankLast[1] == noSymbol) {
+                    while (huffNode[n].nbBits == maxNbBits) n--;
+                    huffNode[n + 1].nbBits--;
+                    rankLast[1] = (u32)(n + 1);
+                    totalCost++;
+                    continue;
+                }
+                huffNode[rankLast[1] + 1].nbBits--;
+                rankLast[1]++;
+                totalCost++;
+            }
+        }
+    }
+    return maxNbBits;
+}
+/* HUF_buildCTable_wksp + HUF_buildCTableFromTree, U/HufCompress.cs:750-823 */
+static size_t huf_buildCTable(zso_huf_ct* ct, const u32* count, u32 maxSV, u32 maxNbBits)
+{
+    zso_node nodes[513]; zso_node* const huffNode = nodes + 1;
+    int nonNullRank, n; u16 nbPerRank[13] = {0}, valPerRank[13] = {0};
+    if (maxNbBits == 0) maxNbBits = 11;
+    if (maxSV > 255) return ZSO_ERR(maxSymbolValue_tooLarge);
+    memset(nodes, 0, sizeof nodes);
+    huf_sort(huffNode, count, maxSV);
+    nonNullRank = huf_buildTree(huffNode, maxSV);
+    maxNbBits = huf_setMaxHeight(huffNode, (u32)nonNullRank, maxNbBits);
+    if (maxNbBits > 12) return ZSO_ERR(GENERIC);
+    for (n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+    {   u16 min = 0;
+        for (n = (int)maxNbBits; n > 0; n--) { valPerRank[n] = min; min += nbPerRank[n]; min >>= 1; }
+    }
+    memset(ct->nbBits, 0, sizeof ct->nbBits); memset(ct->val, 0, sizeof ct->val);
+    for (n = 0; n <= (int)maxSV; n++) ct->nbBits[huffNode[n].byte] = huffNode[n].nbBits;
+    for (n = 0; n <= (int)maxSV; n++) ct->val[n] = valPerRank[ct->nbBits[n]]++;
+    ct->tableLog = maxNbBits; ct->maxSV = maxSV; ct->valid = 1;
+    return maxNbBits;
+}
+size_t zso_huf_buildLengths(u8* nbBits, const u32* count, u32 maxSV, u32 maxNbBits)
+{
+    zso_huf_ct ct; size_t const r = huf_buildCTable(&ct, count, maxSV, maxNbBits);
+    if (!zso_isError(r)) memcpy(nbBits, ct.nbBits, maxSV + 1);
+    return r;
+}
+
+/* HUF_compressWeights, U/HufCompress.cs:40-125 */
+static size_t huf_compressWeights(void* dst, size_t cap, const u8* weights, size_t wtSize)
+{
+    u8* const ostart = (u8*)dst; u8* op = ostart; u8* const oend = ostart + cap;
+    u32 maxSV = 12, tableLog = 6, count[13]; s16 norm[13]; zso_fse_ct ct;
+    if (wtSize <= 1) return 0;
+    {   u32 const maxCount = zso_hist(count, &maxSV, weights, wtSize);
+        if (maxCount == wtSize) return 1;     /* only a single symbol: rle */
+        if (maxCount == 1) return 0;          /* each symbol present at most once: not compressible */
+    }
+    tableLog = zso_fse_optimalTableLog(tableLog, wtSize, maxSV, 2);
+    {   size_t const e = zso_fse_normalizeCount(norm, tableLog, count, wtSize, maxSV, 0); if (zso_isError(e)) return e; }
+    {   size_t const h = zso_fse_writeNCount(op, (size_t)(oend - op), norm, maxSV, tableLog); if (zso_isError(h)) return h; op += h; }
+    {   size_t const e = zso_fse_buildCTable(&ct, norm, maxSV, tableLog); if (zso_isError(e)) return e; }
+    {   size_t const c = zso_fse_compress(op, (size_t)(oend - op), weights, wtSize, &ct);
+        if (zso_isError(c)) return c;
+        if (c == 0) return 0;
+        op += c;
+    }
+    return (size_t)(op - ostart);
+}
+/* HUF_writeCTable_wksp, U/HufCompress.cs:168-235 */
+static size_t huf_writeCTable(void* dst, size_t maxDst, const zso_huf_ct* ct, u32 maxSV, u32 huffLog)
+{
+    u8 bitsToWeight[13], huffWeight[256]; u8* op = (u8*)dst; u32 n;
+    bitsToWeight[0] = 0;
+    for (n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
+    for (n = 0; n < maxSV; n++) huffWeight[n] = bitsToWeight[ct->nbBits[n]];
+    if (maxDst < 1) return ZSO_ERR(dstSize_tooSmall);
+    {   size_t const hSize = huf_compressWeights(op + 1, maxDst - 1, huffWeight, maxSV);
+        if (zso_isError(hSize)) return hSize;
+        if (hSize > 1 && hSize < maxSV / 2) { op[0] = (u8)hSize; return hSize + 1; }
+    }
+    if (maxSV > 128) return ZSO_ERR(GENERIC);
+    if (((maxSV + 1) / 2) + 1 > maxDst) return ZSO_ERR(dstSize_tooSmall);
+    op[0] = (u8)(128 + (maxSV - 1));
+    huffWeight[maxSV] = 0;
+    for (n = 0; n < maxSV; n += 2) op[(n / 2) + 1] = (u8)((huffWeight[n] << 4) + huffWeight[n + 1]);
+    return ((maxSV + 1) / 2) + 1;
+}
+/* HUF_compress1X_usingCTable_internal_body, U/HufCompress.cs:1056-1189: symbols last-to-first, then end mark */
+static size_t huf_compress1X(void* dst, size_t cap, const u8* src, size_t n, const zso_huf_ct* ct)
+{
+    zso_bitc b; size_t i;
+    if (cap < 8) return 0;
+    if (zso_isError(bitc_init(&b, dst, cap))) return 0;
+    for (i = n; i-- > 0; ) bitc_add(&b, ct->val[src[i]], ct->nbBits[src[i]]);
+    return bitc_close(&b);
+}
+/* HUF_compress4X_usingCTable_internal, U/HufCompress.cs:1221-1321 */
+static size_t huf_compress4X(void* dst, size_t cap, const u8* src, size_t n, const zso_huf_ct* ct)
+{
+    size_t const seg = (n + 3) / 4; const u8* ip = src; const u8* const iend = src + n;
+    u8* const ostart = (u8*)dst; u8* const oend = ostart + cap; u8* op = ostart; int k;
+    if (cap < 6 + 1 + 1 + 1 + 8) return 0;
+    if (n < 12) return 0;
+    op += 6;
+    for (k = 0; k < 4; k++) {
+        size_t const len = (k < 3) ? seg : (size_t)(iend - ip);
+        size_t const c = huf_compress1X(op, (size_t)(oend - op), ip, len, ct);
+        if (c == 0 || c > 65535) return 0;
+        if (k < 3) zso_writeLE16(ostart + 2 * k, (u32)c);
+        op += c; ip += len;
+    }
+    return (size_t)(op - ostart);
+}
+/* HUF_validateCTable / HUF_estimateCompressedSize, U/HufCompress.cs:825-860 */
+static int huf_validateCTable(const zso_huf_ct* ct, const u32* count, u32 maxSV)
+{
+    u32 s; int bad = 0;
+    for (s = 0; s <= maxSV; s++) bad |= (count[s] != 0) & (ct->nbBits[s] == 0);
+    return !bad;
+}
+static size_t huf_estimate(const zso_huf_ct* ct, const u32* count, u32 maxSV)
+{
+    size_t nb = 0; u32 s;
+    for (s = 0; s <= maxSV; s++) nb += (size_t)ct->nbBits[s] * count[s];
+    return nb >> 3;
+}
+/* HUF_compressCTable_internal, U/HufCompress.cs:1336-1358 */
+static size_t huf_body(u8* ostart, u8* op, u8* oend, const u8* src, size_t srcSize, int singleStream, const zso_huf_ct* ct)
+{
+    size_t const c = singleStream ? huf_compress1X(op, (size_t)(oend - op), src, srcSize, ct)
+                                  : huf_compress4X(op, (size_t)(oend - op), src, srcSize, ct);
+    if (c == 0) return 0;
+    op += c;
+    if ((size_t)(op - ostart) >= srcSize - 1) return 0;
+    return (size_t)(op - ostart);
+}
+/* HUF_compress_internal, U/HufCompress.cs:1360-1543 */
+static size_t huf_compress(void* dst, size_t dstSize, const u8* src, size_t srcSize, int singleStream,
+                           zso_huf_ct* oldTable, int* repeat, int preferRepeat, u32 suspectUncompressible)
+{
+    u8* const ostart = (u8*)dst; u8* const oend = ostart + dstSize; u8* op = ostart;
+    u32 count[256], maxSV = 255, huffLog = 11; zso_huf_ct table;
+    if (!srcSize || !dstSize) return 0;
+    if (srcSize > 128 * 1024) return ZSO_ERR(srcSize_wrong);
+    if (preferRepeat && *repeat == HUF_repeat_valid) return huf_body(ostart, op, oend, src, srcSize, singleStream, oldTable);
+    if (suspectUncompressible && srcSize >= 4096 * 10) {
+        u32 m1 = 255, m2 = 255; size_t largestTotal = 0;
+        largestTotal += zso_hist(count, &m1, src, 4096);
+        largestTotal += zso_hist(count, &m2, src + srcSize - 4096, 4096);
+        if (largestTotal <= ((2 * 4096) >> 7) + 4) return 0;
+    }
+    {   size_t const largest = zso_hist(count, &maxSV, src, srcSize);
+        if (largest == srcSize) { *ostart = src[0]; return 1; }
+        if (largest <= (srcSize >> 7) + 4) return 0;
+    }
+    if (*repeat == HUF_repeat_check && !huf_validateCTable(oldTable, count, maxSV)) *repeat = HUF_repeat_none;
+    if (preferRepeat && *repeat != HUF_repeat_none) return huf_body(ostart, op, oend, src, srcSize, singleStream, oldTable);
+    huffLog = zso_fse_optimalTableLog(huffLog, srcSize, maxSV, 1);
+    {   size_t const maxBits = huf_buildCTable(&table, count, maxSV, huffLog);
+        if (zso_isError(maxBits)) return maxBits;
+        huffLog = (u32)maxBits;
+    }
+    {   size_t const hSize = huf_writeCTable(op, dstSize, &table, maxSV, huffLog);
+        if (zso_isError(hSize)) return hSize;
+        if (*repeat != HUF_repeat_none) {
+            size_t const oldSize = huf_estimate(oldTable, count, maxSV), newSize = huf_estimate(&table, count, maxSV);
+            if (oldSize <= hSize + newSize || hSize + 12 >= srcSize) return huf_body(ostart, op, oend, src, srcSize, singleStream, oldTable);
+        }
+        if (hSize + 12 >= srcSize) return 0;
+        op += hSize;
+        *repeat = HUF_repeat_none;
+        *oldTable = table;
+    }
+    return huf_body(ostart, op, oend, src, srcSize, singleStream, &table);
+}
+
+/* ------------------------------------------------------------------ */
+/*  block entropy state                                                */
+/* ------------------------------------------------------------------ */
+enum { FSE_repeat_none = 0, FSE_repeat_check = 1, FSE_repeat_valid = 2 };
+typedef struct {
+    zso_huf_ct huf; int hufRepeat;
+    zso_fse_ct ll, of, ml; int llRepeat, ofRepeat, mlRepeat;
+    u32 rep[3];
+} zso_bstate;
+
+static void bstate_reset(zso_bstate* s)     /* ZSTD_reset_compressedBlockState, U/ZstdCompress.cs:2419-2433 */
+{
+    memset(s, 0, sizeof *s);
+    s->rep[0] = 1; s->rep[1] = 4; s->rep[2] = 8;
+    s->hufRepeat = HUF_repeat_none; s->llRepeat = s->ofRepeat = s->mlRepeat = FSE_repeat_none;
+}
+
+static size_t zso_minGain(size_t srcSize) { return (srcSize >> 6) + 2; }   /* strategies < btultra */
+
+/* ZSTD_noCompressLiterals / ZSTD_compressRleLiteralsBlock, U/ZstdCompressLiterals.cs:8-83 */
+static size_t lit_raw(void* dst, size_t cap, const u8* src, size_t n)
+{
+    u8* const o = (u8*)dst; u32 const flSize = 1 + (n > 31) + (n > 4095);
+    if (n + flSize > cap) return ZSO_ERR(dstSize_tooSmall);
+    switch (flSize) {
+    case 1: o[0] = (u8)(0 + (n << 3)); break;
+    case 2: zso_writeLE16(o, (u32)(0 + (1 << 2) + (n << 4))); break;
+    default: zso_writeLE32(o, (u32)(0 + (3 << 2) + (n << 4))); break;
+    }
+    memcpy(o + flSize, src, n);
+    return n + flSize;
+}
+static size_t lit_rle(void* dst, size_t cap, const u8* src, size_t n)
+{
+    u8* const o = (u8*)dst; u32 const flSize = 1 + (n > 31) + (n > 4095);
+    (void)cap;
+    switch (flSize) {
+    case 1: o[0] = (u8)(1 + (n << 3)); break;
+    case 2: zso_writeLE16(o, (u32)(1 + (1 << 2) + (n << 4))); break;
+    default: zso_writeLE32(o, (u32)(1 + (3 << 2) + (n << 4))); break;
+    }
+    o[flSize] = src[0];
+    return flSize + 1;
+}
+/* ZSTD_compressLiterals, U/ZstdCompressLiterals.cs:86-185 */
+static size_t zso_compressLiterals(const zso_bstate* prev, zso_bstate* next, u32 strategy, int disableLiteralCompression,
+                                   void* dst, size_t cap, const u8* src, size_t srcSize, u32 suspectUncompressible)
+{
+    size_t const minGain = zso_minGain(srcSize);
+    size_t const lhSize = 3 + (srcSize >= 1024) + (srcSize >= 16384);
+    u8* const ostart = (u8*)dst; int singleStream = srcSize < 256; u32 hType = 2; size_t cLitSize;
+    next->huf = prev->huf; next->hufRepeat = prev->hufRepeat;
+    if (disableLiteralCompression) return lit_raw(dst, cap, src, srcSize);
+    {   size_t const minLitSize = (prev->hufRepeat == HUF_repeat_valid) ? 6 : 63;
+        if (srcSize <= minLitSize) return lit_raw(dst, cap, src, srcSize);
+    }
+    if (cap < lhSize + 1) return ZSO_ERR(dstSize_tooSmall);
+    {   int repeat = prev->hufRepeat;
+        int const preferRepeat = strategy < ZSO_lazy ? srcSize <= 1024 : 0;
+        if (repeat == HUF_repeat_valid && lhSize == 3) singleStream = 1;
+        cLitSize = huf_compress(ostart + lhSize, cap - lhSize, src, srcSize, singleStream, &next->huf, &repeat, preferRepeat, suspectUncompressible);
+        if (repeat != HUF_repeat_none) hType = 3;     /* reused the previous table */
+    }
+    if (cLitSize == 0 || cLitSize >= srcSize - minGain || zso_isError(cLitSize)) {
+        next->huf = prev->huf; next->hufRepeat = prev->hufRepeat;
+        return lit_raw(dst, cap, src, srcSize);
+    }
+    if (cLitSize == 1) {
+        next->huf = prev->huf; next->hufRepeat = prev->hufRepeat;
+        return lit_rle(dst, cap, src, srcSize);
+    }
+    if (hType == 2) next->hufRepeat = HUF_repeat_check;
+    switch (lhSize) {
+    case 3: zso_writeLE24(ostart, hType + ((u32)!singleStream << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 14)); break;
+    case 4: zso_writeLE32(ostart, hType + (2 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 18)); break;
+    default: zso_writeLE32(ostart, hType + (3 << 2) + ((u32)srcSize << 4) + ((u32)cLitSize << 22)); ostart[4] = (u8)(cLitSize >> 10); break;
+    }
+    return lhSize + cLitSize;
+}
+
+/* ------------------------------------------------------------------ */
+/*  sequences                                                          */
+/* ------------------------------------------------------------------ */
+static const u8 ZSO_LL_Code[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+    22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
+static const u8 ZSO_ML_Code[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+    32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+    40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+    42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
+static inline u32 zso_LLcode(u32 ll) { return ll > 63 ? zso_highbit32(ll) + 19 : ZSO_LL_Code[ll]; }
+static inline u32 zso_MLcode(u32 ml) { return ml > 127 ? zso_highbit32(ml) + 36 : ZSO_ML_Code[ml]; }
+
+typedef struct {
+    zso_seq* seqs; size_t nbSeq, cap;
+    u8* lit; size_t litSize;
+    u32 longLengthType, longLengthPos;      /* 0 none, 1 literalLength, 2 matchLength (ZSTD_longLengthType_e) */
+    u8 *llCode, *mlCode, *ofCode;
+} zso_seqstore;
+
+/* ZSTD_selectEncodingType (strategy < lazy branch), U/ZstdCompressSequences.cs:400-469 */
+static u32 zso_selectEncodingType(int* repeatMode, size_t mostFrequent, size_t nbSeq, u32 defaultNormLog, int isDefaultAllowed, u32 strategy)
+{
+    if (mostFrequent == nbSeq) {
+        *repeatMode = FSE_repeat_none;
+        if (isDefaultAllowed && nbSeq <= 2) return 0;   /* set_basic */
+        return 1;                                        /* set_rle */
+    }
+    /* strategy >= lazy would compare estimated costs; the oracle only restates levels whose strategy is < lazy */
+    if (isDefaultAllowed) {
+        size_t const mult = 10 - strategy, dynamicFse_nbSeq_min = (((size_t)1 << defaultNormLog) * mult) >> 3;
+        if (*repeatMode == FSE_repeat_valid && nbSeq < 1000) return 3;   /* set_repeat */
+        if (nbSeq < dynamicFse_nbSeq_min || mostFrequent < (nbSeq >> (defaultNormLog - 1))) { *repeatMode = FSE_repeat_none; return 0; }
+    }
+    *repeatMode = FSE_repeat_check;
+    return 2;   /* set_compressed */
+}
+/* ZSTD_buildCTable, U/ZstdCompressSequences.cs:471-582 */
+static size_t zso_buildSeqCTable(void* dst, size_t cap, zso_fse_ct* next, u32 FSELog, u32 type, u32* count, u32 max,
+                                 const u8* codeTable, size_t nbSeq, const s16* defaultNorm, u32 defaultNormLog, u32 defaultMax,
+                                 const zso_fse_ct* prev)
+{
+    u8* op = (u8*)dst;
+    switch (type) {
+    case 1: zso_fse_buildCTable_rle(next, (u8)max); if (!cap) return ZSO_ERR(dstSize_tooSmall); *op = codeTable[0]; return 1;
+    case 3: *next = *prev; return 0;
+    case 0: { size_t const e = zso_fse_buildCTable(next, defaultNorm, defaultMax, defaultNormLog); return zso_isError(e) ? e : 0; }
+    default: {
+        s16 norm[64]; size_t nbSeq_1 = nbSeq;
+        u32 const tableLog = zso_fse_optimalTableLog(FSELog, nbSeq, max, 2);
+        if (count[codeTable[nbSeq - 1]] > 1) { count[codeTable[nbSeq - 1]]--; nbSeq_1--; }
+        {   size_t const e = zso_fse_normalizeCount(norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048); if (zso_isError(e)) return e; }
+        {   size_t const n = zso_fse_writeNCount(op, cap, norm, max, tableLog);
+            if (zso_isError(n)) return n;
+            {   size_t const e = zso_fse_buildCTable(next, norm, max, tableLog); if (zso_isError(e)) return e; }
+            return n;
+        } }
+    }
+}
+
+/* ZSTD_encodeSequences_body, U/ZstdCompressSequences.cs:585-704 (64-bit, no long offsets) */
+static size_t zso_encodeSequences(void* dst, size_t cap, const zso_fse_ct* ctML, const u8* mlCode,
+                                  const zso_fse_ct* ctOF, const u8* ofCode, const zso_fse_ct* ctLL, const u8* llCode,
+                                  const zso_seq* seqs, size_t nbSeq)
+{
+    zso_bitc b; zso_cstate sML, sOF, sLL; size_t n;
+    if (zso_isError(bitc_init(&b, dst, cap))) return ZSO_ERR(dstSize_tooSmall);
+    cstate_init2(&sML, ctML, mlCode[nbSeq - 1]);
+    cstate_init2(&sOF, ctOF, ofCode[nbSeq - 1]);
+    cstate_init2(&sLL, ctLL, llCode[nbSeq - 1]);
+    bitc_add(&b, seqs[nbSeq - 1].litLength, ZSO_LL_bits[llCode[nbSeq - 1]]);
+    bitc_add(&b, seqs[nbSeq - 1].mlBase, ZSO_ML_bits[mlCode[nbSeq - 1]]);
+    bitc_add(&b, seqs[nbSeq - 1].offBase, ofCode[nbSeq - 1]);
+    for (n = nbSeq - 1; n-- > 0; ) {
+        u8 const ll = llCode[n], of = ofCode[n], ml = mlCode[n];
+        cstate_encode(&b, &sOF, of);
+        cstate_encode(&b, &sML, ml);
+        cstate_encode(&b, &sLL, ll);
+        bitc_add(&b, seqs[n].litLength, ZSO_LL_bits[ll]);
+        bitc_add(&b, seqs[n].mlBase, ZSO_ML_bits[ml]);
+        bitc_add(&b, seqs[n].offBase, of);
+    }
+    cstate_flush(&b, &sML); cstate_flush(&b, &sOF); cstate_flush(&b, &sLL);
+    {   size_t const sz = bitc_close(&b); if (!sz) return ZSO_ERR(dstSize_tooSmall); return sz; }
+}
+
+/* ZSTD_entropyCompressSeqStore_internal, U/ZstdCompress.cs:3236-3354 */
+static size_t zso_entropyCompressSeqStore_internal(zso_seqstore* ss, const zso_bstate* prev, zso_bstate* next,
+                                                   u32 strategy, int disableLiteralCompression, void* dst, size_t cap)
+{
+    u8* const ostart = (u8*)dst; u8* const oend = ostart + cap; u8* op = ostart;
+    size_t const nbSeq = ss->nbSeq; size_t lastCountSize = 0; u32 count[64];
+    {   u32 const suspect = (nbSeq == 0) || (ss->litSize / nbSeq >= 20);
+        size_t const c = zso_compressLiterals(prev, next, strategy, disableLiteralCompression, op, cap, ss->lit, ss->litSize, suspect);
+        if (zso_isError(c)) return c;
+        op += c;
+    }
+    if (oend - op < 3 + 1) return ZSO_ERR(dstSize_tooSmall);
+    if (nbSeq < 128) *op++ = (u8)nbSeq;
+    else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
+    else { op[0] = 0xFF; zso_writeLE16(op + 1, (u32)(nbSeq - 0x7F00)); op += 3; }
+    if (nbSeq == 0) {
+        next->ll = prev->ll; next->of = prev->of; next->ml = prev->ml;
+        next->llRepeat = prev->llRepeat; next->ofRepeat = prev->ofRepeat; next->mlRepeat = prev->mlRepeat;
+        return (size_t)(op - ostart);
+    }
+    {   u8* const seqHead = op++; u32 LLtype, OFtype, MLtype; size_t n;
+        /* ZSTD_seqToCodes, U/ZstdCompress.cs:3069-3098 */
+        for (n = 0; n < nbSeq; n++) {
+            ss->llCode[n] = (u8)zso_LLcode(ss->seqs[n].litLength);
+            ss->ofCode[n] = (u8)zso_highbit32(ss->seqs[n].offBase);
+            ss->mlCode[n] = (u8)zso_MLcode(ss->seqs[n].mlBase);
+        }
+        if (ss->longLengthType == 1) ss->llCode[ss->longLengthPos] = ZSO_MaxLL;
+        if (ss->longLengthType == 2) ss->mlCode[ss->longLengthPos] = ZSO_MaxML;
+        /* ZSTD_buildSequencesStatistics, U/ZstdCompress.cs:3127-3233 */
+        {   u32 max = ZSO_MaxLL; size_t const mf = zso_hist(count, &max, ss->llCode, nbSeq); size_t cs;
+            next->llRepeat = prev->llRepeat;
+            LLtype = zso_selectEncodingType(&next->llRepeat, mf, nbSeq, ZSO_LL_DEFAULTNORMLOG, 1, strategy);
+            cs = zso_buildSeqCTable(op, (size_t)(oend - op), &next->ll, ZSO_LLFSELog, LLtype, count, max, ss->llCode, nbSeq, ZSO_LL_defaultNorm, ZSO_LL_DEFAULTNORMLOG, ZSO_MaxLL, &prev->ll);
+            if (zso_isError(cs)) return cs;
+            if (LLtype == 2) lastCountSize = cs;
+            op += cs;
+        }
+        {   u32 max = ZSO_MaxOff; size_t const mf = zso_hist(count, &max, ss->ofCode, nbSeq); size_t cs;
+            int const defaultAllowed = max <= 28;
+            next->ofRepeat = prev->ofRepeat;
+            OFtype = zso_selectEncodingType(&next->ofRepeat, mf, nbSeq, ZSO_OF_DEFAULTNORMLOG, defaultAllowed, strategy);
+            cs = zso_buildSeqCTable(op, (size_t)(oend - op), &next->of, ZSO_OffFSELog, OFtype, count, max, ss->ofCode, nbSeq, ZSO_OF_defaultNorm, ZSO_OF_DEFAULTNORMLOG, 28, &prev->of);
+            if (zso_isError(cs)) return cs;
+            if (OFtype == 2) lastCountSize = cs;
+            op += cs;
+        }
+        {   u32 max = ZSO_MaxML; size_t const mf = zso_hist(count, &max, ss->mlCode, nbSeq); size_t cs;
+            next->mlRepeat = prev->mlRepeat;
+            MLtype = zso_selectEncodingType(&next->mlRepeat, mf, nbSeq, ZSO_ML_DEFAULTNORMLOG, 1, strategy);
+            cs = zso_buildSeqCTable(op, (size_t)(oend - op), &next->ml, ZSO_MLFSELog, MLtype, count, max, ss->mlCode, nbSeq, ZSO_ML_defaultNorm, ZSO_ML_DEFAULTNORMLOG, ZSO_MaxML, &prev->ml);
+            if (zso_isError(cs)) return cs;
+            if (MLtype == 2) lastCountSize = cs;
+            op += cs;
+        }
+        *seqHead = (u8)((LLtype << 6) + (OFtype << 4) + (MLtype << 2));
+    }
+    {   size_t const bs = zso_encodeSequences(op, (size_t)(oend - op), &next->ml, ss->mlCode, &next->of, ss->ofCode, &next->ll, ss->llCode, ss->seqs, nbSeq);
+        if (zso_isError(bs)) return bs;
+        op += bs;
+        if (lastCountSize && (lastCountSize + bs) < 4) return 0;   /* 1.3.4 decoder quirk, :3346-3350 */
+    }
+    return (size_t)(op - ostart);
+}
+/* ZSTD_entropyCompressSeqStore, U/ZstdCompress.cs:3357-3392 */
+static size_t zso_entropyCompressSeqStore(zso_seqstore* ss, const zso_bstate* prev, zso_bstate* next, u32 strategy,
+                                          int disableLiteralCompression, void* dst, size_t cap, size_t srcSize)
+{
+    size_t const c = zso_entropyCompressSeqStore_internal(ss, prev, next, strategy, disableLiteralCompression, dst, cap);
+    if (c == 0) return 0;
+    if (c == ZSO_ERR(dstSize_tooSmall) && srcSize <= cap) return 0;
+    if (zso_isError(c)) return c;
+    if (c >= srcSize - zso_minGain(srcSize)) return 0;
+    return c;
+}
+
+/* ------------------------------------------------------------------ */
+/*  fast match finder                                                  */
+/* ------------------------------------------------------------------ */
+static inline size_t zso_hashPtr(const u8* p, u32 hBits, u32 mls)
+{
+    switch (mls) {
+    default:
+    case 4: return (zso_readLE32(p) * 2654435761U) >> (32 - hBits);
+    case 5: return (size_t)(((zso_readLE64(p) << (64 - 40)) * 889523592379ULL) >> (64 - hBits));
+    case 6: return (size_t)(((zso_readLE64(p) << (64 - 48)) * 227718039650203ULL) >> (64 - hBits));
+    case 7: return (size_t)(((zso_readLE64(p) << (64 - 56)) * 58295818150454627ULL) >> (64 - hBits));
+    case 8: return (size_t)((zso_readLE64(p) * 0xCF1BBCDCB7A56463ULL) >> (64 - hBits));
+    }
+}
+static size_t zso_count(const u8* ip, const u8* match, const u8* iend)
+{
+    const u8* const start = ip;
+    while (ip < iend && *ip == *match) { ip++; match++; }
+    return (size_t)(ip - start);
+}
+static void zso_storeSeq(zso_seqstore* ss, size_t litLength, const u8* literals, u32 offCode, size_t mlBase)
+{
+    memcpy(ss->lit + ss->litSize, literals, litLength); ss->litSize += litLength;
+    if (litLength > 0xFFFF) { ss->longLengthType = 1; ss->longLengthPos = (u32)ss->nbSeq; }
+    ss->seqs[ss->nbSeq].litLength = (u16)litLength;
+    ss->seqs[ss->nbSeq].offBase = offCode + 1;
+    if (mlBase > 0xFFFF) { ss->longLengthType = 2; ss->longLengthPos = (u32)ss->nbSeq; }
+    ss->seqs[ss->nbSeq].mlBase = (u16)mlBase;
+    ss->nbSeq++;
+}
+
+/* the match state that persists across the blocks of one frame */
+typedef struct {
+    zso_cparams cp;
+    const u8* base;            /* index i <-> base + i ; the first source byte has index 2 (U/ZstdCompressInternal.cs:723-732) */
+    u32 dictLimit, lowLimit;
+    u32* hashTable;
+} zso_mstate;
+
+static u32 ms_lowestPrefixIndex(const zso_mstate* ms, u32 curr, u32 windowLog)
+{
+    u32 const maxDistance = 1u << windowLog, lowestValid = ms->dictLimit;
+    return (curr - lowestValid > maxDistance) ? curr - maxDistance : lowestValid;
+}
+
+/* ZSTD_compressBlock_fast_noDict_generic, U/ZstdFast.cs:96-288.  Returns the trailing-literals size. */
+static size_t zso_compressBlock_fast(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize)
+{
+    u32* const hashTable = ms->hashTable;
+    u32 const hlog = ms->cp.hashLog, mls = ms->cp.minMatch;
+    size_t const stepSize = (ms->cp.targetLength > 1) ? (ms->cp.targetLength + !ms->cp.targetLength + 1) : 2;
+    const u8* const base = ms->base; const u8* const istart = src;
+    u32 const endIndex = (u32)((size_t)(istart - base) + srcSize);
+    u32 const prefixStartIndex = ms_lowestPrefixIndex(ms, endIndex, ms->cp.windowLog);
+    const u8* const prefixStart = base + prefixStartIndex;
+    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8;
+    const u8* anchor = istart; const u8* ip0 = istart; const u8 *ip1, *ip2, *ip3;
+    u32 current0, rep1 = rep[0], rep2 = rep[1], offsetSaved = 0;
+    size_t hash0, hash1; u32 idx, mval, offcode; const u8* match0; size_t mLength, step; const u8* nextStep;
+    size_t const kStepIncr = 1 << 7;
+    if (srcSize < 8) return srcSize;   /* not reachable from the block loop (blocks < 7 bytes are stored raw, and ilimit guards the rest) */
+    ip0 += (ip0 == prefixStart);
+    {   u32 const curr = (u32)(ip0 - base), windowLow = ms_lowestPrefixIndex(ms, curr, ms->cp.windowLog), maxRep = curr - windowLow;
+        if (rep2 > maxRep) { offsetSaved = rep2; rep2 = 0; }
+        if (rep1 > maxRep) { offsetSaved = rep1; rep1 = 0; }
+    }
+    for (;;) {      /* _start */
+        int found = 0;     /* 1 = repcode match at ip2, 2 = hash-table match at ip0 */
+        step = stepSize; nextStep = ip0 + kStepIncr;
+        ip1 = ip0 + 1; ip2 = ip0 + step; ip3 = ip2 + 1;
+        if (ip3 >= ilimit) break;
+        hash0 = zso_hashPtr(ip0, hlog, mls); hash1 = zso_hashPtr(ip1, hlog, mls);
+        idx = hashTable[hash0];
+        do {
+            u32 const rval = zso_readLE32(ip2 - rep1);
+            current0 = (u32)(ip0 - base); hashTable[hash0] = current0;
+            if (zso_readLE32(ip2) == rval && rep1 > 0) {
+                ip0 = ip2; match0 = ip0 - rep1;
+                mLength = ip0[-1] == match0[-1];
+                ip0 -= mLength; match0 -= mLength;
+                offcode = 0; mLength += 4;
+                found = 1; break;
+            }
+            mval = (idx >= prefixStartIndex) ? zso_readLE32(base + idx) : zso_readLE32(ip0) ^ 1;
+            if (zso_readLE32(ip0) == mval) { found = 2; break; }
+            idx = hashTable[hash1]; hash0 = hash1; hash1 = zso_hashPtr(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip3;
+            current0 = (u32)(ip0 - base); hashTable[hash0] = current0;
+            mval = (idx >= prefixStartIndex) ? zso_readLE32(base + idx) : zso_readLE32(ip0) ^ 1;
+            if (zso_readLE32(ip0) == mval) { found = 2; break; }
+            idx = hashTable[hash1]; hash0 = hash1; hash1 = zso_hashPtr(ip2, hlog, mls);
+            ip0 = ip1; ip1 = ip2; ip2 = ip0 + step; ip3 = ip1 + step;
+            if (ip2 >= nextStep) { step++; nextStep += kStepIncr; }
+        } while (ip3 < ilimit);
+        if (!found) break;      /* _cleanup */
+        if (found == 2) {       /* _offset */
+            match0 = base + idx;
+            rep2 = rep1; rep1 = (u32)(ip0 - match0);
+            offcode = rep1 + 2; mLength = 4;
+            while (ip0 > anchor && match0 > prefixStart && ip0[-1] == match0[-1]) { ip0--; match0--; mLength++; }
+        }
+        /* _match */
+        mLength += zso_count(ip0 + mLength, match0 + mLength, iend);
+        zso_storeSeq(ss, (size_t)(ip0 - anchor), anchor, offcode, mLength - 3);
+        ip0 += mLength; anchor = ip0;
+        if (ip1 < ip0) hashTable[hash1] = (u32)(ip1 - base);
+        if (ip0 <= ilimit) {
+            hashTable[zso_hashPtr(base + current0 + 2, hlog, mls)] = current0 + 2;
+            hashTable[zso_hashPtr(ip0 - 2, hlog, mls)] = (u32)(ip0 - 2 - base);
+            if (rep2 > 0) {
+                while (ip0 <= ilimit && zso_readLE32(ip0) == zso_readLE32(ip0 - rep2)) {
+                    size_t const rLength = zso_count(ip0 + 4, ip0 + 4 - rep2, iend) + 4;
+                    { u32 const t = rep2; rep2 = rep1; rep1 = t; }
+                    hashTable[zso_hashPtr(ip0, hlog, mls)] = (u32)(ip0 - base);
+                    ip0 += rLength;
+                    zso_storeSeq(ss, 0, anchor, 0, rLength - 3);
+                    anchor = ip0;
+                }
+            }
+        }
+    }
+    rep[0] = rep1 ? rep1 : offsetSaved;
+    rep[1] = rep2 ? rep2 : offsetSaved;
+    return (size_t)(iend - anchor);
+}
+
+/* ------------------------------------------------------------------ */
+/*  frame                                                              */
+/* ------------------------------------------------------------------ */
+/* ZSTD_writeFrameHeader, U/ZstdCompress.cs:4817-4929 (no dictID, contentSizeFlag = 1) */
+static size_t zso_writeFrameHeader(u8* op, size_t cap, u32 windowLog, u64 pledged, int checksumFlag)
+{
+    u32 const windowSize = 1u << windowLog;
+    u32 const single = windowSize >= pledged;
+    u32 const fcsCode = (pledged >= 256) + (pledged >= 65536 + 256) + (pledged >= 0xFFFFFFFFu);
+    size_t pos = 0;
+    if (cap < 18) return ZSO_ERR(dstSize_tooSmall);
+    zso_writeLE32(op, ZSO_MAGIC); pos = 4;
+    op[pos++] = (u8)(0 + ((u32)(checksumFlag > 0) << 2) + (single << 5) + (fcsCode << 6));
+    if (!single) op[pos++] = (u8)((windowLog - 10) << 3);
+    switch (fcsCode) {
+    case 0: if (single) op[pos++] = (u8)pledged; break;
+    case 1: zso_writeLE16(op + pos, (u32)(pledged - 256)); pos += 2; break;
+    case 2: zso_writeLE32(op + pos, (u32)pledged); pos += 4; break;
+    default: zso_writeLE64(op + pos, pledged); pos += 8; break;
+    }
+    return pos;
+}
+
+static int zso_isRLE(const u8* src, size_t n) { size_t i; for (i = 1; i < n; i++) if (src[i] != src[0]) return 0; return 1; }
+
+static void seqstore_alloc(zso_seqstore* ss, size_t blockSize)
+{
+    size_t const maxNbSeq = blockSize / 3 + 1;      /* the reference divides by 3 for minMatch 3, else 4 (U/ZstdCompress.cs:2570) */
+    memset(ss, 0, sizeof *ss);
+    ss->seqs = (zso_seq*)malloc(maxNbSeq * sizeof(zso_seq)); ss->cap = maxNbSeq;
+    ss->lit = (u8*)malloc(blockSize + 64);
+    ss->llCode = (u8*)malloc(maxNbSeq); ss->mlCode = (u8*)malloc(maxNbSeq); ss->ofCode = (u8*)malloc(maxNbSeq);
+}
+static void seqstore_free(zso_seqstore* ss) { free(ss->seqs); free(ss->lit); free(ss->llCode); free(ss->mlCode); free(ss->ofCode); }
+static void seqstore_reset(zso_seqstore* ss) { ss->nbSeq = 0; ss->litSize = 0; ss->longLengthType = 0; ss->longLengthPos = 0; }
+
+static size_t zso_blockCompressor(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize)
+{
+    /* only the "fast" strategy is restated so far; other strategies are declared unpinned by the callers */
+    return zso_compressBlock_fast(ms, ss, rep, src, srcSize);
+}
+
+size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksumFlag)
+{
+    zso_cparams const cp = zso_getCParams(level, srcSize);
+    u8* const ostart = (u8*)dst; u8* op = ostart; const u8* ip = (const u8*)src; size_t remaining = srcSize;
+    size_t blockSize = (size_t)1 << cp.windowLog; size_t result;
+    zso_mstate ms; zso_seqstore ss; zso_bstate *prev, *next; int isFirstBlock = 1, wroteBlock = 0;
+    int const disableLit = (cp.strategy == ZSO_fast) && (cp.targetLength > 0);
+    if (blockSize > ZSO_BLOCKSIZE_MAX) blockSize = ZSO_BLOCKSIZE_MAX;
+    if (cp.strategy != ZSO_fast) return ZSO_ERR(parameter_unsupported);   /* not restated yet: say so, never substitute */
+    {   size_t const h = zso_writeFrameHeader(op, dstCapacity, cp.windowLog, srcSize, checksumFlag);
+        if (zso_isError(h)) return h;
+        op += h; dstCapacity -= h;
+    }
+    ms.cp = cp; ms.base = ip - 2; ms.dictLimit = ms.lowLimit = 2;
+    ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
+    seqstore_alloc(&ss, blockSize);
+    prev = (zso_bstate*)malloc(sizeof *prev); next = (zso_bstate*)malloc(sizeof *next);
+    bstate_reset(prev); bstate_reset(next);
+    while (remaining) {             /* ZSTD_compress_frameChunk */
+        u32 const lastBlock = blockSize >= remaining;
+        u32 const maxDist = 1u << cp.windowLog;
+        size_t cSize;
+        if (dstCapacity < 3 + 3) { result = ZSO_ERR(dstSize_tooSmall); goto done; }
+        if (remaining < blockSize) blockSize = remaining;
+        {   /* ZSTD_window_enforceMaxDist(window, ip, maxDist) — note: evaluated at the block START */
+            u32 const blockIdx = (u32)(ip - ms.base);
+            if (blockIdx > maxDist) {
+                u32 const newLow = blockIdx - maxDist;
+                if (ms.lowLimit < newLow) ms.lowLimit = newLow;
+                if (ms.dictLimit < ms.lowLimit) ms.dictLimit = ms.lowLimit;
+            }
+        }
+        /* ZSTD_compressBlock_internal */
+        if (blockSize < 1 + 1 + 1 + 3 + 1) cSize = 0;          /* ZSTD_buildSeqStore: too small, don't even try */
+        else {
+            size_t lastLL; int i;
+            seqstore_reset(&ss);
+            for (i = 0; i < 3; i++) next->rep[i] = prev->rep[i];
+            lastLL = zso_blockCompressor(&ms, &ss, next->rep, ip, blockSize);
+            memcpy(ss.lit + ss.litSize, ip + blockSize - lastLL, lastLL); ss.litSize += lastLL;
+            cSize = zso_entropyCompressSeqStore(&ss, prev, next, cp.strategy, disableLit, op + 3, dstCapacity - 3, blockSize);
+            if (!isFirstBlock && cSize < 25 && zso_isRLE(ip, blockSize)) { cSize = 1; op[3] = ip[0]; }
+        }
+        if (!zso_isError(cSize) && cSize > 1) { zso_bstate* t = prev; prev = next; next = t; }   /* confirm repcodes + entropy tables */
+        if (prev->ofRepeat == FSE_repeat_valid) prev->ofRepeat = FSE_repeat_check;
+        if (zso_isError(cSize)) { result = cSize; goto done; }
+        if (cSize == 0) {           /* ZSTD_noCompressBlock */
+            if (blockSize + 3 > dstCapacity) { result = ZSO_ERR(dstSize_tooSmall); goto done; }
+            zso_writeLE24(op, lastBlock + (0u << 1) + (u32)(blockSize << 3));
+            memcpy(op + 3, ip, blockSize);
+            cSize = 3 + blockSize;
+        } else {
+            u32 const h = cSize == 1 ? lastBlock + (1u << 1) + (u32)(blockSize << 3) : lastBlock + (2u << 1) + (u32)(cSize << 3);
+            zso_writeLE24(op, h);
+            cSize += 3;
+        }
+        ip += blockSize; remaining -= blockSize; op += cSize; dstCapacity -= cSize;
+        isFirstBlock = 0; wroteBlock = 1;
+    }
+    /* ZSTD_writeEpilogue */
+    if (!wroteBlock) {
+        if (dstCapacity < 4) { result = ZSO_ERR(dstSize_tooSmall); goto done; }
+        zso_writeLE24(op, 1); op += 3; dstCapacity -= 3;
+    }
+    if (checksumFlag) {
+        if (dstCapacity < 4) { result = ZSO_ERR(dstSize_tooSmall); goto done; }
+        zso_writeLE32(op, (u32)zso_xxh64(src, srcSize, 0)); op += 4;
+    }
+    result = (size_t)(op - ostart);
+done:
+    free(ms.hashTable); seqstore_free(&ss); free(prev); free(next);
+    return result;
+}
+
+size_t zso_compress_chunked(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                            int level, int checksumFlag, size_t chunkSize)
+{
+    const u8* ip = (const u8*)src; u8* op = (u8*)dst; size_t remaining = srcSize;
+    if (srcSize == 0) return zso_compress(dst, dstCapacity, src, 0, level, checksumFlag);
+    while (remaining) {
+        size_t const n = remaining < chunkSize ? remaining : chunkSize;
+        size_t const c = zso_compress(op, dstCapacity, ip, n, level, checksumFlag);
+        if (zso_isError(c)) return c;
+        op += c; dstCapacity -= c; ip += n; remaining -= n;
+    }
+    return (size_t)(op - (u8*)dst);
+}
+
+/* ---------- stage hooks ---------- */
+size_t zso_block_sequences(zso_seq* seqs, size_t seqCap, u8* lits, size_t* litSizePtr,
+                           const void* src, size_t srcSize, int level)
+{
+    zso_cparams const cp = zso_getCParams(level, srcSize);
+    zso_mstate ms; zso_seqstore ss; u32 rep[3] = { 1, 4, 8 }; size_t lastLL, n;
+    ms.cp = cp; ms.base = (const u8*)src - 2; ms.dictLimit = ms.lowLimit = 2;
+    ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
+    seqstore_alloc(&ss, srcSize + 8);
+    lastLL = srcSize < 8 ? srcSize : zso_blockCompressor(&ms, &ss, rep, (const u8*)src, srcSize);
+    memcpy(ss.lit + ss.litSize, (const u8*)src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
+    n = ss.nbSeq < seqCap ? ss.nbSeq : seqCap;
+    memcpy(seqs, ss.seqs, n * sizeof(zso_seq));
+    memcpy(lits, ss.lit, ss.litSize); *litSizePtr = ss.litSize;
+    n = ss.nbSeq;
+    free(ms.hashTable); seqstore_free(&ss);
+    return n;
+}
+
+size_t zso_entropy_block(void* dst, size_t dstCapacity, const zso_seq* seqs, size_t nbSeq,
+                         const u8* lits, size_t litSize, u32 strategy, size_t srcSize)
+{
+    zso_seqstore ss; zso_bstate *prev = (zso_bstate*)malloc(sizeof *prev), *next = (zso_bstate*)malloc(sizeof *next);
+    size_t r;
+    seqstore_alloc(&ss, (litSize > nbSeq * 3 ? litSize : nbSeq * 3) + 8);
+    bstate_reset(prev); bstate_reset(next);
+    memcpy(ss.seqs, seqs, nbSeq * sizeof(zso_seq)); ss.nbSeq = nbSeq;
+    memcpy(ss.lit, lits, litSize); ss.litSize = litSize;
+    r = zso_entropyCompressSeqStore(&ss, prev, next, strategy, 0, dst, dstCapacity, srcSize);
+    seqstore_free(&ss); free(prev); free(next);
+    return r;
+}
