@@ -1,0 +1,117 @@
+/*
+ * zstd_mi355x.h — C ABI of libzstd_mi355x.so, the MI355X (gfx950) block compressor/decompressor that sits
+ * behind ZstdSharp's one-shot path (Compressor.Wrap / Decompressor.Unwrap).
+ *
+ * Every ZSTD_* entry point below keeps the name, argument order, types and error convention of the function the
+ * reference calls at that point, so the reference's own P/Invoke precedent
+ * (/root/reference/src/Zstd.Extern/ExternMethods.cs:8-42: cdecl, IntPtr contexts/buffers, nuint sizes, 32-bit
+ * enums) binds to this library unchanged, and a `Methods`-shaped shim lets Compressor.cs / Decompressor.cs
+ * compile as they are.  Citations: S/ = src/ZstdSharp/, U/ = src/ZstdSharp/Unsafe/.
+ *
+ * Return convention (U/ErrorPrivate.cs:10-24): size_t result; it is an error iff > (size_t)-120, and then
+ * (0 - result) is a ZSTD_ErrorCode (U/ZSTD_ErrorCode.cs).  A too-small destination yields exactly (size_t)-70,
+ * which TryWrap/TryUnwrap test for (S/Compressor.cs:116-120, S/Decompressor.cs:105-109).
+ *
+ * Buffers may be host memory (as the C# callers pass, pinned only for the call) or device memory (HBM): the
+ * library asks the HIP runtime which it is and stages host buffers itself.  Nothing is retained after return.
+ * One context is used by one thread at a time; any number of contexts may be used concurrently.
+ */
+#ifndef ZSTD_MI355X_H
+#define ZSTD_MI355X_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ZSTD_CCtx_s ZSTD_CCtx;
+typedef struct ZSTD_DCtx_s ZSTD_DCtx;
+
+/* U/ZSTD_cParameter.cs / U/ZSTD_dParameter.cs values that the safe API uses */
+enum {
+    ZSTD_c_compressionLevel = 100, ZSTD_c_windowLog = 101, ZSTD_c_hashLog = 102, ZSTD_c_chainLog = 103,
+    ZSTD_c_searchLog = 104, ZSTD_c_minMatch = 105, ZSTD_c_targetLength = 106, ZSTD_c_strategy = 107,
+    ZSTD_c_contentSizeFlag = 200, ZSTD_c_checksumFlag = 201, ZSTD_c_dictIDFlag = 202, ZSTD_c_nbWorkers = 400,
+    ZSTD_d_windowLogMax = 100
+};
+
+/* ---- compression context: S/Compressor.cs:32,60,138 -> U/ZstdCompress.cs:24-27, 43-62, 137-160 ---- */
+ZSTD_CCtx* ZSTD_createCCtx(void);
+size_t     ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                   /* NULL is accepted */
+/* S/Compressor.cs:48-54 -> U/ZstdCompress.cs:819-884, 1270-1283 */
+size_t     ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, int param, int value);
+size_t     ZSTD_CCtx_getParameter(const ZSTD_CCtx* cctx, int param, int* value);
+/* S/Compressor.cs:39 (dictionary load): no dictionary support on the GPU path -> parameter_unsupported unless size 0 */
+size_t     ZSTD_CCtx_loadDictionary(ZSTD_CCtx* cctx, const void* dict, size_t dictSize);
+/* S/Compressor.cs:73-76 -> U/ZstdCompress.cs:19-22 */
+size_t     ZSTD_compressBound(size_t srcSize);
+/* S/Compressor.cs:94 -> U/ZstdCompress.cs:7138-7177 */
+size_t     ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+/* B/Benchmark.cs:67, X/ExternMethods.cs:17-18 -> U/ZstdCompress.cs:5772-5776 */
+size_t     ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
+/* S/Compressor.cs:8-9 -> U/ZstdCompress.cs:7762-7770 */
+int        ZSTD_minCLevel(void);
+int        ZSTD_maxCLevel(void);
+int        ZSTD_defaultCLevel(void);
+
+/* ---- decompression context: S/Decompressor.cs:12,25,124 -> U/ZstdDecompress.cs:326-395 ---- */
+ZSTD_DCtx* ZSTD_createDCtx(void);
+size_t     ZSTD_freeDCtx(ZSTD_DCtx* dctx);
+size_t     ZSTD_DCtx_setParameter(ZSTD_DCtx* dctx, int param, int value);   /* S/Decompressor.cs:41-46 */
+size_t     ZSTD_DCtx_getParameter(ZSTD_DCtx* dctx, int param, int* value);
+size_t     ZSTD_DCtx_loadDictionary(ZSTD_DCtx* dctx, const void* dict, size_t dictSize);   /* S/Decompressor.cs:32 */
+/* S/Decompressor.cs:53 -> U/ZstdDecompress.cs:971-993 ; error = (unsigned long long)-2 (S/ThrowHelper.cs:7-8) */
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize);
+size_t     ZSTD_findFrameCompressedSize(const void* src, size_t srcSize);
+/* S/Decompressor.cs:86 -> U/ZstdDecompress.cs:1365-1368 */
+size_t     ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+
+/* ---- errors: S/ThrowHelper.cs:12-13 -> U/ErrorPrivate.cs:10-24, 35-120 ---- */
+unsigned    ZSTD_isError(size_t code);
+const char* ZSTD_getErrorName(size_t code);
+unsigned    ZSTD_versionNumber(void);        /* 10501, as U/ZstdCommon.cs:11-21 */
+const char* ZSTD_versionString(void);
+
+/* ---- streaming entry points of the safe API (S/Compressor.cs:114, S/Decompressor.cs:103): not part of this
+ *      path yet; exported so the shim links, they return parameter_unsupported ---- */
+typedef struct { const void* src; size_t size; size_t pos; } ZSTD_inBuffer;
+typedef struct { void* dst; size_t size; size_t pos; } ZSTD_outBuffer;
+size_t ZSTD_compressStream2(ZSTD_CCtx* cctx, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp);
+size_t ZSTD_decompressStream(ZSTD_DCtx* dctx, ZSTD_outBuffer* output, ZSTD_inBuffer* input);
+
+/* =====================================================================================================
+ * Extensions (not in the reference): device selection, HBM-resident calls, per-stage timing, and test hooks.
+ * ===================================================================================================== */
+int    ZSTDMI_deviceCount(void);                       /* number of visible MI355X devices; 0 => every call fails loudly */
+size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* cctx, int device);
+size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* dctx, int device);
+/* run on a caller-owned HIP stream (e.g. torch's current stream); NULL restores the context's own stream */
+size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* cctx, void* hipStream);
+size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* dctx, void* hipStream);
+
+/* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
+size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);
+size_t ZSTDMI_decompressDevice(ZSTD_DCtx* dctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);
+
+/* per-stage HIP-event timing of the LAST call (enable first).  Fills up to `cap` entries, returns the count. */
+size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* cctx, int enable);
+size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* dctx, int enable);
+int    ZSTDMI_CCtx_getStageTimes(const ZSTD_CCtx* cctx, float* ms, const char** names, int cap);
+int    ZSTDMI_DCtx_getStageTimes(const ZSTD_DCtx* dctx, float* ms, const char** names, int cap);
+
+/* test hooks (kernel-level parity against the oracle) */
+typedef struct { unsigned offBase; unsigned short litLength; unsigned short mlBase; } ZSTDMI_Seq;
+/* sequences + literals the match finder produced for chunk `chunkIdx` of the last ZSTDMI/ZSTD compress call */
+size_t ZSTDMI_debugGetChunk(ZSTD_CCtx* cctx, size_t chunkIdx, ZSTDMI_Seq* seqs, size_t seqCap, size_t* nbSeq,
+                            void* lits, size_t litCap, size_t* litSize);
+/* entropy-code ONE caller-supplied seqStore with the GPU kernels; returns the compressed block body size
+ * (0 = "store raw", the reference's ZSTD_entropyCompressSeqStore convention) */
+size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const ZSTDMI_Seq* seqs, size_t nbSeq,
+                                const void* lits, size_t litSize, size_t srcSize);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,640 @@
+// decode.hip — zstd frame decoder on gfx950 (SURVEY.md §8 a-13 … a-17).
+//
+//   frame_walk_kernel    : ZSTD_findFrameSizeInfo over the whole input (U/ZstdDecompress.cs:877-951, 971-993):
+//                          headers only, produces the work list {srcOff, dstOff, srcSize, dstSize} per frame.
+//   decode_frames_kernel : one wave per frame (ZSTD_decompressFrame, U/ZstdDecompress.cs:1062-1214).  Frames are
+//                          independent (ZSTD_decompressBegin resets repcodes/tables per frame, :1933-1954), blocks
+//                          inside a frame are not (window history, repcodes, repeat tables), so the frame is the
+//                          unit of GPU parallelism.  Inside a block: Huffman weights + X1 table in LDS
+//                          (HUF_readStats U/EntropyCommon.cs:292-402, HUF_readDTableX1 U/HufDecompress.cs:80-251),
+//                          the four literal streams on four lanes (U/HufDecompress.cs:342-537), FSE sequence tables
+//                          in LDS (U/ZstdDecompressBlock.cs:1571-1943), the serial sequence state chain on lane 0
+//                          (:2360-2484) and 64-lane cooperative literal / match copies (:2187-2262).
+// Results are bit-exact with the reference decoder by construction of the format; error codes follow
+// U/ZSTD_ErrorCode.cs (first failing frame wins).
+#include "zmi_device.h"
+
+namespace zmi {
+
+// ------------------------------------------------------------------------------------------------
+// frame walk
+// ------------------------------------------------------------------------------------------------
+struct FrameHeader { u64 contentSize; u64 windowSize; u32 headerSize; u32 checksum; u32 dictID; u32 err; };
+
+__device__ inline FrameHeader parse_frame_header(const u8* p, u64 avail)
+{
+    FrameHeader h; h.contentSize = ~0ull; h.windowSize = 0; h.headerSize = 0; h.checksum = 0; h.dictID = 0; h.err = 0;
+    if (avail < 5) { h.err = kErrSrcSizeWrong; return h; }
+    if (readLE32(p) != 0xFD2FB528u) { h.err = kErrPrefixUnknown; return h; }
+    const u8 fhd = p[4];
+    const u32 didCode = fhd & 3, single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    const u32 didSize = didCode == 3 ? 4 : didCode, fcsSize = fcsId == 0 ? (single ? 1 : 0) : (1u << fcsId);
+    const u32 fhs = 5 + !single + didSize + fcsSize;
+    if (avail < fhs) { h.err = kErrSrcSizeWrong; return h; }
+    if (fhd & 0x08) { h.err = kErrFrameParameterUnsupported; return h; }
+    u32 pos = 5;
+    if (!single) {
+        const u8 wl = p[pos++]; const u32 wlog = (wl >> 3) + 10;
+        if (wlog > 31) { h.err = kErrWindowTooLarge; return h; }
+        h.windowSize = 1ull << wlog; h.windowSize += (h.windowSize >> 3) * (wl & 7);
+    }
+    if (didCode == 1) h.dictID = p[pos]; else if (didCode == 2) h.dictID = readLE16(p + pos); else if (didCode == 3) h.dictID = readLE32(p + pos);
+    pos += didSize;
+    switch (fcsId) {
+    case 0: if (single) h.contentSize = p[pos]; break;
+    case 1: h.contentSize = (u64)readLE16(p + pos) + 256; break;
+    case 2: h.contentSize = readLE32(p + pos); break;
+    default: h.contentSize = readLE64(p + pos); break;
+    }
+    if (single) h.windowSize = h.contentSize;
+    h.headerSize = fhs; h.checksum = (fhd >> 2) & 1;
+    return h;
+}
+
+__global__ void frame_walk_kernel(const u8* __restrict__ src, u64 srcSize, FrameDesc* __restrict__ frames, u32 maxFrames, u32* __restrict__ status)
+{
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    u64 pos = 0, dstOff = 0; u32 n = 0, err = 0;
+    while (srcSize - pos >= 5) {            // ZSTD_decompressMultiFrame loop condition (U/ZstdDecompress.cs:1228)
+        const u8* p = src + pos; const u64 avail = srcSize - pos;
+        const u32 magic = readLE32(p);
+        if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+            if (avail < 8) { err = kErrSrcSizeWrong; break; }
+            const u64 sz = (u64)readLE32(p + 4) + 8;
+            if (sz > avail) { err = kErrSrcSizeWrong; break; }
+            pos += sz; continue;
+        }
+        const FrameHeader h = parse_frame_header(p, avail);
+        if (h.err) { err = (h.err == kErrPrefixUnknown && n > 0) ? kErrSrcSizeWrong : h.err; break; }
+        if (h.dictID) { err = kErrDictionaryWrong; break; }
+        if (h.contentSize == ~0ull) { err = kErrFrameParameterUnsupported; break; }   // GPU path needs sized frames
+        u64 q = pos + h.headerSize;
+        for (;;) {
+            if (srcSize - q < 3) { err = kErrSrcSizeWrong; break; }
+            const u32 bh = readLE24(src + q);
+            const u32 last = bh & 1, type = (bh >> 1) & 3; u32 cSize = bh >> 3;
+            if (type == 3) { err = kErrCorruption; break; }
+            if (type == 1) cSize = 1;
+            if (3 + (u64)cSize > srcSize - q) { err = kErrSrcSizeWrong; break; }
+            q += 3 + cSize;
+            if (last) break;
+        }
+        if (err) break;
+        if (h.checksum) { if (srcSize - q < 4) { err = kErrSrcSizeWrong; break; } q += 4; }
+        if (n >= maxFrames || (q - pos) > 0xFFFFFFFFull || h.contentSize > 0xFFFFFFFFull) { err = kErrMemoryAllocation; break; }
+        FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.srcSize = (u32)(q - pos); f.dstSize = (u32)h.contentSize;
+        frames[n++] = f;
+        dstOff += h.contentSize; pos = q;
+    }
+    if (!err && pos != srcSize) err = kErrSrcSizeWrong;     // trailing garbage (U/ZstdDecompress.cs:1309-1312)
+    status[0] = n; status[1] = err; status[2] = (u32)dstOff; status[3] = (u32)(dstOff >> 32);
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward bit reader over global memory (U/Bitstream.cs:172-426)
+// ------------------------------------------------------------------------------------------------
+struct BackBits {
+    const u8* base; s32 size;   // stream bytes
+    s32 pos;                    // unread bits; < 0 after an over-read (the reference's BIT_DStream_overflow)
+    u64 win; s32 wStart;        // 64 stream bits starting at bit wStart
+
+    __device__ __forceinline__ void load_window(s32 endBit)        // window that ends at the byte holding endBit-1
+    {
+        s32 endByte = (endBit + 7) >> 3;
+        if (endByte > size) endByte = size;
+        s32 b0 = endByte - 8;
+        if (b0 >= 0) { win = readLE64(base + b0); wStart = b0 * 8; }
+        else {
+            u64 v = 0;
+            for (s32 i = 0; i < 8; i++) { const s32 k = b0 + i; if (k >= 0 && k < size) v |= (u64)base[k] << (8 * i); }
+            win = v; wStart = b0 * 8;                                // negative start: low bits read as zero
+        }
+    }
+    // returns false when the stream is malformed (empty, or no end mark)
+    __device__ __forceinline__ bool init(const u8* p, s32 n)
+    {
+        base = p; size = n; pos = 0; win = 0; wStart = 0;
+        if (n < 1) return false;
+        const u32 last = p[n - 1];
+        if (last == 0) return false;
+        pos = (n - 1) * 8 + (s32)highbit32(last);
+        load_window(pos);
+        return true;
+    }
+    __device__ __forceinline__ u32 peek(u32 nb)                      // next nb bits (nb <= 32), zeros below bit 0
+    {
+        const s32 lo = pos - (s32)nb;
+        if (lo < wStart) load_window(pos);
+        const s32 sh = lo - wStart;
+        const u64 v = sh >= 0 ? (win >> sh) : (win << (-sh));       // sh < 0 only when reading below the stream start
+        return nb ? (u32)(v & ((1ull << nb) - 1)) : 0u;
+    }
+    __device__ __forceinline__ u32 read(u32 nb) { const u32 v = peek(nb); pos -= (s32)nb; return v; }
+};
+
+// ------------------------------------------------------------------------------------------------
+// per-wave decoder state in LDS
+// ------------------------------------------------------------------------------------------------
+struct SeqSym { u16 nextState; u8 nbAddBits; u8 nbBits; u32 baseValue; };
+
+struct DecLds {
+    u16 huf[4096];              // X1 table: byte | nbBits << 8
+    SeqSym ll[512], ml[512], of[256];
+    u8  weights[256];
+    s16 norm[256];
+    u16 symbolNext[256];
+    u32 rankStart[16];
+    u32 llLog, mlLog, ofLog, hufLog;
+    u32 llValid, mlValid, ofValid, hufValid;
+    // FSE scratch for Huffman weights (tableLog <= 6)
+    u16 wNewState[64]; u8 wSymbol[64]; u8 wNbBits[64];
+    u32 bcast[8];
+};
+
+__constant__ u8  dLL_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+__constant__ u32 dLL_base[36] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,18,20,22,24,28,32,40,48,64,0x80,0x100,0x200,0x400,0x800,0x1000,0x2000,0x4000,0x8000,0x10000 };
+__constant__ u8  dML_bits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+__constant__ u32 dML_base[53] = { 3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,32,33,34,
+                                  35,37,39,41,43,47,51,59,67,83,99,0x83,0x103,0x203,0x403,0x803,0x1003,0x2003,0x4003,0x8003,0x10003 };
+__constant__ s16 dLL_defaultNorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+__constant__ s16 dML_defaultNorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                         1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+__constant__ s16 dOF_defaultNorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+__device__ __forceinline__ u32 of_base(u32 code) { return code == 0 ? 0u : code == 1 ? 1u : (1u << code) - 3u; }   // OF_base, U/ZstdDecompressInternal.cs:85
+
+// forward bit cursor (FSE_readNCount_body, U/EntropyCommon.cs:52-242); zeros beyond `size`
+__device__ __forceinline__ u32 fwd_bits(const u8* p, u32 size, u32 bitpos, u32 n)
+{
+    u64 acc = 0; const u32 b0 = bitpos >> 3;
+    if (b0 + 8 <= size) acc = readLE64(p + b0);
+    else for (u32 i = 0; i < 8; i++) if (b0 + i < size) acc |= (u64)p[b0 + i] << (8 * i);
+    return (u32)((acc >> (bitpos & 7)) & ((1ull << n) - 1));
+}
+
+// returns bytes consumed, 0 on error
+__device__ inline u32 read_ncount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const u8* ip, u32 srcSize)
+{
+    u32 bitpos, nbBits, remaining, threshold, charnum = 0; const u32 maxSV1 = *maxSVPtr + 1; bool previous0 = false;
+    if (srcSize < 1) return 0;
+    for (u32 s = 0; s < maxSV1; s++) norm[s] = 0;
+    nbBits = fwd_bits(ip, srcSize, 0, 4) + 5;
+    if (nbBits > 15) return 0;
+    bitpos = 4; *tableLogPtr = nbBits;
+    remaining = (1u << nbBits) + 1; threshold = 1u << nbBits; nbBits++;
+    for (;;) {
+        if (previous0) {
+            for (;;) {
+                const u32 r = fwd_bits(ip, srcSize, bitpos, 2);
+                bitpos += 2; charnum += r;
+                if (r != 3) break;
+                if (bitpos > srcSize * 8 + 32) return 0;
+            }
+            if (charnum >= maxSV1) break;
+        }
+        {
+            const u32 max = (2 * threshold - 1) - remaining; int count;
+            const u32 low = fwd_bits(ip, srcSize, bitpos, nbBits - 1);
+            if (low < max) { count = (int)low; bitpos += nbBits - 1; }
+            else { u32 v = fwd_bits(ip, srcSize, bitpos, nbBits); if (v >= threshold) v -= max; count = (int)v; bitpos += nbBits; }
+            count--;
+            remaining -= count >= 0 ? (u32)count : 1u;
+            norm[charnum++] = (s16)count;
+            previous0 = count == 0;
+            if (remaining < threshold) {
+                if (remaining <= 1) break;
+                nbBits = highbit32(remaining) + 1; threshold = 1u << (nbBits - 1);
+            }
+            if (charnum >= maxSV1) break;
+        }
+    }
+    if (remaining != 1 || charnum > maxSV1) return 0;
+    *maxSVPtr = charnum - 1;
+    const u32 used = (bitpos + 7) >> 3;
+    return used > srcSize ? 0 : used;
+}
+
+// ZSTD_buildFSETable_body (U/ZstdDecompressBlock.cs:1571-1710), one lane
+__device__ inline void build_seq_dtable(SeqSym* t, u16* symbolNext, const s16* norm, u32 maxSV, u32 tableLog, int kind /*0 LL,1 OF,2 ML*/)
+{
+    const u32 tableSize = 1u << tableLog; u32 highThreshold = tableSize - 1;
+    for (u32 s = 0; s <= maxSV; s++) {
+        if (norm[s] == -1) { t[highThreshold--].baseValue = s; symbolNext[s] = 1; }
+        else symbolNext[s] = (u16)norm[s];
+    }
+    {
+        const u32 mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3; u32 pos = 0;
+        for (u32 s = 0; s <= maxSV; s++)
+            for (int i = 0; i < norm[s]; i++) {
+                t[pos].baseValue = s;
+                pos = (pos + step) & mask;
+                while (pos > highThreshold) pos = (pos + step) & mask;
+            }
+    }
+    for (u32 u = 0; u < tableSize; u++) {
+        const u32 sym = t[u].baseValue, nextState = symbolNext[sym]++;
+        SeqSym e; e.nbBits = (u8)(tableLog - highbit32(nextState));
+        e.nextState = (u16)((nextState << e.nbBits) - tableSize);
+        if (kind == 0) { e.nbAddBits = dLL_bits[sym]; e.baseValue = dLL_base[sym]; }
+        else if (kind == 1) { e.nbAddBits = (u8)sym; e.baseValue = of_base(sym); }
+        else { e.nbAddBits = dML_bits[sym]; e.baseValue = dML_base[sym]; }
+        t[u] = e;
+    }
+}
+
+// ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), one lane.  Returns bytes consumed or 0xFFFFFFFF on error.
+__device__ inline u32 set_seq_table(DecLds& L, SeqSym* t, u32* logPtr, u32* validPtr, u32 type, u32 max, u32 maxLog,
+                                    const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax)
+{
+    switch (type) {
+    case 1: {
+        if (!srcSize) return 0xFFFFFFFFu;
+        const u32 sym = src[0];
+        if (sym > max) return 0xFFFFFFFFu;
+        SeqSym e; e.nextState = 0; e.nbBits = 0;
+        if (kind == 0) { e.nbAddBits = dLL_bits[sym]; e.baseValue = dLL_base[sym]; }
+        else if (kind == 1) { e.nbAddBits = (u8)sym; e.baseValue = of_base(sym); }
+        else { e.nbAddBits = dML_bits[sym]; e.baseValue = dML_base[sym]; }
+        t[0] = e; *logPtr = 0; *validPtr = 1;
+        return 1; }
+    case 0:
+        for (u32 s = 0; s <= defMax; s++) L.norm[s] = defNorm[s];
+        build_seq_dtable(t, L.symbolNext, L.norm, defMax, defLog, kind);
+        *logPtr = defLog; *validPtr = 1;
+        return 0;
+    case 3:
+        return *validPtr ? 0 : 0xFFFFFFFFu;
+    default: {
+        u32 maxSV = max, tableLog = 0;
+        const u32 hs = read_ncount(L.norm, &maxSV, &tableLog, src, srcSize);
+        if (!hs || tableLog > maxLog) return 0xFFFFFFFFu;
+        build_seq_dtable(t, L.symbolNext, L.norm, maxSV, tableLog, kind);
+        *logPtr = tableLog; *validPtr = 1;
+        return hs; }
+    }
+}
+
+// HUF_readStats (weights) on lane 0; returns bytes consumed or 0 on error.  nbSymbols/tableLog out.
+__device__ inline u32 huf_read_stats(DecLds& L, const u8* ip, u32 srcSize, u32* nbSymbolsPtr, u32* tableLogPtr)
+{
+    if (!srcSize) return 0;
+    u32 iSize = ip[0], oSize;
+    if (iSize >= 128) {
+        oSize = iSize - 127; iSize = (oSize + 1) / 2;
+        if (iSize + 1 > srcSize) return 0;
+        for (u32 n = 0; n < oSize; n += 2) { L.weights[n] = ip[1 + n / 2] >> 4; L.weights[n + 1] = ip[1 + n / 2] & 15; }
+    } else {
+        if (iSize + 1 > srcSize) return 0;
+        // FSE_decompress_wksp with maxLog 6 (U/FseDecompress.cs:230-446)
+        u32 maxSV = 255, tableLog = 0;
+        const u32 hs = read_ncount(L.norm, &maxSV, &tableLog, ip + 1, iSize);
+        if (!hs || tableLog > 6) return 0;
+        {   // FSE_buildDTable
+            const u32 tableSize = 1u << tableLog; u32 highThreshold = tableSize - 1;
+            for (u32 s = 0; s <= maxSV; s++) {
+                if (L.norm[s] == -1) { L.wSymbol[highThreshold--] = (u8)s; L.symbolNext[s] = 1; } else L.symbolNext[s] = (u16)L.norm[s];
+            }
+            const u32 mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3; u32 pos = 0;
+            for (u32 s = 0; s <= maxSV; s++)
+                for (int i = 0; i < L.norm[s]; i++) { L.wSymbol[pos] = (u8)s; pos = (pos + step) & mask; while (pos > highThreshold) pos = (pos + step) & mask; }
+            if (pos != 0) return 0;
+            for (u32 u = 0; u < tableSize; u++) {
+                const u32 sym = L.wSymbol[u], nextState = L.symbolNext[sym]++;
+                const u32 nb = tableLog - highbit32(nextState);
+                L.wNbBits[u] = (u8)nb; L.wNewState[u] = (u16)((nextState << nb) - tableSize);
+            }
+        }
+        BackBits bd;
+        if (!bd.init(ip + 1 + hs, (s32)(iSize - hs))) return 0;
+        u32 s1 = bd.read(tableLog), s2 = bd.read(tableLog); u32 n = 0;
+        for (;;) {
+            if (n + 2 > 255) return 0;
+            L.weights[n++] = L.wSymbol[s1]; s1 = L.wNewState[s1] + bd.read(L.wNbBits[s1]);
+            if (bd.pos < 0) { L.weights[n++] = L.wSymbol[s2]; break; }
+            if (n + 2 > 255) return 0;
+            L.weights[n++] = L.wSymbol[s2]; s2 = L.wNewState[s2] + bd.read(L.wNbBits[s2]);
+            if (bd.pos < 0) { L.weights[n++] = L.wSymbol[s1]; break; }
+        }
+        oSize = n;
+    }
+    u32 weightTotal = 0, rank1 = 0;
+    for (u32 n = 0; n < oSize; n++) {
+        const u32 w = L.weights[n];
+        if (w > 12) return 0;
+        weightTotal += (1u << w) >> 1; rank1 += w == 1;
+    }
+    if (!weightTotal) return 0;
+    const u32 tableLog = highbit32(weightTotal) + 1;
+    if (tableLog > 12) return 0;
+    const u32 rest = (1u << tableLog) - weightTotal;
+    if ((1u << highbit32(rest)) != rest) return 0;
+    const u32 lastWeight = highbit32(rest) + 1;
+    L.weights[oSize] = (u8)lastWeight; rank1 += lastWeight == 1;
+    if (rank1 < 2 || (rank1 & 1)) return 0;
+    *nbSymbolsPtr = oSize + 1; *tableLogPtr = tableLog;
+    return iSize + 1;
+}
+
+// one Huffman stream on one lane (HUF_decodeStreamX1, U/HufDecompress.cs:264-309); returns false on corruption
+__device__ inline bool huf_decode_stream(const u16* __restrict__ table, u32 tableLog, const u8* src, u32 srcSize, u8* __restrict__ out, u32 n)
+{
+    BackBits bd;
+    if (!bd.init(src, (s32)srcSize)) return false;
+    for (u32 i = 0; i < n; i++) {
+        const u32 e = table[bd.peek(tableLog)];
+        out[i] = (u8)e;
+        bd.pos -= (s32)(e >> 8);
+    }
+    return bd.pos == 0;
+}
+
+// 64-lane copies inside one wave; dst/src may be arbitrarily aligned
+__device__ __forceinline__ void wave_copy(u8* __restrict__ d, const u8* __restrict__ s, u32 n, u32 lane)
+{
+    for (u32 i = lane; i < n; i += 64) d[i] = s[i];
+}
+// match copy with the byte-wise overlap semantics of ZSTD_execSequence (U/ZstdDecompressBlock.cs:2247-2259):
+// every byte i of the match equals the byte `offset` behind it, so byte i = src0[i % offset] over the bytes that
+// existed before the match started.
+__device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 lane)
+{
+    const u8* s0 = d - offset;
+    if (offset >= n) { for (u32 i = lane; i < n; i += 64) d[i] = s0[i]; }
+    else { for (u32 i = lane; i < n; i += 64) d[i] = s0[i % offset]; }
+}
+
+constexpr u32 kBlockMax = 1u << 17;
+constexpr u32 kScratchPerFrame = kBlockMax + 256;     // literal buffer of the current block
+
+// decodes one frame with one wave; returns 0 or a ZSTD_ErrorCode.  Every branch below is wave-uniform.
+__device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out, u8* __restrict__ litBuf, const u32 lane)
+{
+#define FAIL(code) return (code)
+    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);     // validated by the walk; re-read for sizes/flags
+    u32 ip = h.headerSize;          // offset inside the frame
+    u32 op = 0;                     // bytes produced
+    u32 rep0 = 1, rep1 = 4, rep2 = 8;
+    if (lane == 0) { L.llValid = L.mlValid = L.ofValid = L.hufValid = 0; }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+
+    for (;;) {
+        if (fd.srcSize - ip < 3) FAIL(kErrSrcSizeWrong);
+        const u32 bh = readLE24(fsrc + ip);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        ip += 3;
+        if (type == 3) FAIL(kErrCorruption);
+        if (type == 0) {
+            if (bsz > fd.srcSize - ip) FAIL(kErrSrcSizeWrong);
+            if (bsz > fd.dstSize - op) FAIL(kErrCorruption);
+            wave_copy(out + op, fsrc + ip, bsz, lane);
+            op += bsz; ip += bsz;
+        } else if (type == 1) {
+            if (1 > fd.srcSize - ip) FAIL(kErrSrcSizeWrong);
+            if (bsz > fd.dstSize - op) FAIL(kErrCorruption);
+            const u8 b = fsrc[ip];
+            for (u32 i = lane; i < bsz; i += 64) out[op + i] = b;
+            op += bsz; ip += 1;
+        } else {
+            // ---------------- compressed block (ZSTD_decompressBlock_internal, U/ZstdDecompressBlock.cs:3090-3154) ----------------
+            if (bsz > fd.srcSize - ip) FAIL(kErrSrcSizeWrong);
+            if (bsz >= kBlockMax) FAIL(kErrSrcSizeWrong);
+            if (bsz < 3) FAIL(kErrCorruption);
+            const u8* const b = fsrc + ip; const u32 bend = bsz;
+            u32 bp = 0;
+            const u8* lit; u32 litSize;
+            {   // ---- literals section (ZSTD_decodeLiteralsBlock, :88-396) ----
+                const u32 ltype = b[0] & 3, lhl = (b[0] >> 2) & 3;
+                if (ltype >= 2) {
+                    if (bsz < 5) FAIL(kErrCorruption);
+                    const u32 lhc = readLE32(b);
+                    u32 lhSize, litCSize; bool single = false;
+                    switch (lhl) {
+                    case 0: case 1: single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; break;
+                    case 2: lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; break;
+                    default: lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((u32)b[4] << 10); break;
+                    }
+                    if (litSize > kBlockMax) FAIL(kErrCorruption);
+                    if (litCSize + lhSize > bsz) FAIL(kErrCorruption);
+                    const u8* hsrc = b + lhSize; u32 hlen = litCSize;
+                    if (ltype == 2) {
+                        u32 nbSymbols = 0, tableLog = 0, hs = 0;
+                        if (lane == 0) { hs = huf_read_stats(L, hsrc, hlen, &nbSymbols, &tableLog); }
+                        hs = uniform(hs); nbSymbols = uniform(nbSymbols); tableLog = uniform(tableLog);
+                        if (!hs || hs >= hlen) FAIL(kErrCorruption);
+                        // HUF_readDTableX1: rank starts on lane 0, table fill by all lanes
+                        if (lane == 0) {
+                            u32 cnt[13]; for (int i = 0; i < 13; i++) cnt[i] = 0;
+                            for (u32 n = 0; n < nbSymbols; n++) cnt[L.weights[n]]++;
+                            u32 next = 0;
+                            for (u32 w = 1; w <= tableLog; w++) { L.rankStart[w] = next; next += cnt[w] << (w - 1); }
+                            // per-symbol start offsets: reuse symbolNext as u16 start index (<= 4096)
+                            for (u32 n = 0; n < nbSymbols; n++) {
+                                const u32 w = L.weights[n];
+                                if (w) { L.symbolNext[n] = (u16)L.rankStart[w]; L.rankStart[w] += (1u << w) >> 1; }
+                            }
+                            L.hufLog = tableLog; L.hufValid = 1;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        for (u32 n = lane; n < nbSymbols; n += 64) {
+                            const u32 w = L.weights[n];
+                            if (w) {
+                                const u32 len = (1u << w) >> 1, start = L.symbolNext[n];
+                                const u16 e = (u16)(n | ((tableLog + 1 - w) << 8));
+                                for (u32 u = 0; u < len; u++) L.huf[start + u] = e;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        hsrc += hs; hlen -= hs;
+                    } else {
+                        if (!uniform(L.hufValid)) FAIL(kErrDictionaryCorrupted);
+                    }
+                    const u32 tableLog = uniform(L.hufLog);
+                    bool ok = true;
+                    if (single) {
+                        if (lane == 0) ok = huf_decode_stream(L.huf, tableLog, hsrc, hlen, litBuf, litSize);
+                    } else {
+                        if (hlen < 10) FAIL(kErrCorruption);
+                        const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
+                        const u32 seg = (litSize + 3) / 4;
+                        if (6 + l1 + l2 + l3 > hlen) FAIL(kErrCorruption);
+                        if (seg * 3 > litSize) FAIL(kErrCorruption);
+                        const u32 l4 = hlen - 6 - l1 - l2 - l3;
+                        if (lane < 4) {
+                            const u32 so = lane == 0 ? 6 : lane == 1 ? 6 + l1 : lane == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
+                            const u32 sl = lane == 0 ? l1 : lane == 1 ? l2 : lane == 2 ? l3 : l4;
+                            const u32 on = lane < 3 ? seg : litSize - 3 * seg;
+                            ok = huf_decode_stream(L.huf, tableLog, hsrc + so, sl, litBuf + lane * seg, on);
+                        }
+                    }
+                    if (ballot(!ok)) FAIL(kErrCorruption);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    lit = litBuf; bp = lhSize + litCSize;
+                } else {
+                    u32 lhSize;
+                    switch (lhl) {
+                    case 0: case 2: lhSize = 1; litSize = b[0] >> 3; break;
+                    case 1: lhSize = 2; litSize = readLE16(b) >> 4; break;
+                    default: lhSize = 3; litSize = readLE24(b) >> 4; break;
+                    }
+                    if (litSize > kBlockMax) FAIL(kErrCorruption);
+                    if (ltype == 0) {
+                        if (lhSize + litSize > bsz) FAIL(kErrCorruption);
+                        lit = b + lhSize; bp = lhSize + litSize;
+                    } else {
+                        if (lhSize + 1 > bsz) FAIL(kErrCorruption);
+                        const u8 v = b[lhSize];
+                        for (u32 i = lane; i < litSize; i += 64) litBuf[i] = v;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        lit = litBuf; bp = lhSize + 1;
+                    }
+                }
+            }
+            // ---- sequences header (ZSTD_decodeSeqHeaders, :1845-1943) ----
+            if (bp >= bend) FAIL(kErrSrcSizeWrong);
+            u32 nbSeq = b[bp++];
+            if (!nbSeq) { if (bp != bend) FAIL(kErrSrcSizeWrong); }
+            else {
+                if (nbSeq > 0x7F) {
+                    if (nbSeq == 0xFF) { if (bp + 2 > bend) FAIL(kErrSrcSizeWrong); nbSeq = readLE16(b + bp) + 0x7F00; bp += 2; }
+                    else { if (bp >= bend) FAIL(kErrSrcSizeWrong); nbSeq = ((nbSeq - 0x80) << 8) + b[bp++]; }
+                }
+                if (bp + 1 > bend) FAIL(kErrSrcSizeWrong);
+                const u32 modes = b[bp++];
+                u32 adv = 0;
+                if (lane == 0) {
+                    u32 p = bp, r;
+                    r = set_seq_table(L, L.ll, &L.llLog, &L.llValid, modes >> 6, 35, 9, b + p, bend - p, 0, dLL_defaultNorm, 6, 35);
+                    if (r == 0xFFFFFFFFu) adv = r; else { p += r;
+                    r = set_seq_table(L, L.of, &L.ofLog, &L.ofValid, (modes >> 4) & 3, 31, 8, b + p, bend - p, 1, dOF_defaultNorm, 5, 28);
+                    if (r == 0xFFFFFFFFu) adv = r; else { p += r;
+                    r = set_seq_table(L, L.ml, &L.mlLog, &L.mlValid, (modes >> 2) & 3, 52, 9, b + p, bend - p, 2, dML_defaultNorm, 6, 52);
+                    if (r == 0xFFFFFFFFu) adv = r; else { p += r; adv = p - bp; } } }
+                }
+                adv = uniform(adv);
+                if (adv == 0xFFFFFFFFu) FAIL(kErrCorruption);
+                bp += adv;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            }
+            // ---- sequences (ZSTD_decompressSequences_body, :2668-2763) ----
+            u32 litPos = 0;
+            if (nbSeq) {
+                BackBits bd; bool okInit = true;
+                u32 sLL = 0, sOF = 0, sML = 0;
+                if (lane == 0) {
+                    okInit = bd.init(b + bp, (s32)(bend - bp));
+                    if (okInit) { sLL = bd.read(L.llLog); sOF = bd.read(L.ofLog); sML = bd.read(L.mlLog); }
+                }
+                if (!uniform(okInit ? 1u : 0u)) FAIL(kErrCorruption);
+                for (u32 n = 0; n < nbSeq; n++) {
+                    u32 litLength = 0, matchLength = 0, offset = 0;
+                    if (lane == 0) {     // ZSTD_decodeSequence (:2360-2484)
+                        const SeqSym ll = L.ll[sLL], ml = L.ml[sML], of = L.of[sOF];
+                        matchLength = ml.baseValue; litLength = ll.baseValue;
+                        if (of.nbAddBits > 1) {
+                            offset = of.baseValue + bd.read(of.nbAddBits);
+                            rep2 = rep1; rep1 = rep0; rep0 = offset;
+                        } else {
+                            const u32 ll0 = ll.baseValue == 0;
+                            if (of.nbAddBits == 0) {
+                                offset = ll0 ? rep1 : rep0;
+                                rep1 = ll0 ? rep0 : rep1;
+                                rep0 = offset;
+                            } else {
+                                const u32 code = of.baseValue + ll0 + bd.read(1);
+                                u32 temp = code == 3 ? rep0 - 1 : (code == 1 ? rep1 : code == 2 ? rep2 : rep0);
+                                temp += !temp;
+                                if (code != 1) rep2 = rep1;
+                                rep1 = rep0; rep0 = temp; offset = temp;
+                            }
+                        }
+                        if (ml.nbAddBits) matchLength += bd.read(ml.nbAddBits);
+                        if (ll.nbAddBits) litLength += bd.read(ll.nbAddBits);
+                        sLL = ll.nextState + bd.read(ll.nbBits);
+                        sML = ml.nextState + bd.read(ml.nbBits);
+                        sOF = of.nextState + bd.read(of.nbBits);
+                    }
+                    litLength = uniform(litLength); matchLength = uniform(matchLength); offset = uniform(offset);
+                    // ZSTD_execSequence (:2187-2262)
+                    if (litLength > litSize - litPos) FAIL(kErrCorruption);
+                    if ((u64)litLength + matchLength > fd.dstSize - op) FAIL(kErrCorruption);
+                    wave_copy(out + op, lit + litPos, litLength, lane);
+                    op += litLength; litPos += litLength;
+                    if (offset > op) FAIL(kErrCorruption);
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // earlier stores of this wave are visible to the match reads
+                    wave_match_copy(out + op, offset, matchLength, lane);
+                    op += matchLength;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+                u32 leftover = 0;
+                if (lane == 0) leftover = bd.pos > 0;
+                if (uniform(leftover)) FAIL(kErrCorruption);          // bitstream not fully consumed (:2730-2733)
+            }
+            {
+                const u32 lastLL = litSize - litPos;
+                if (lastLL > fd.dstSize - op) FAIL(kErrCorruption);
+                wave_copy(out + op, lit + litPos, lastLL, lane);
+                op += lastLL;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+            ip += bsz;
+        }
+        if (last) break;
+    }
+    if (op != fd.dstSize) FAIL(kErrCorruption);           // regenerated size must equal the header's FCS (U/ZstdDecompress.cs:1177-1184)
+    if (h.checksum) {
+        // XXH64 of the regenerated frame: accumulators on lanes 0..3 (U/ZstdDecompress.cs:1186-1208)
+        const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+        auto rotl = [](u64 x, int r) { return (x << r) | (x >> (64 - r)); };
+        auto rnd = [&](u64 acc, u64 in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
+        const u32 n = fd.dstSize, stripes = n >> 5, j = lane & 3;
+        u64 v = j == 0 ? P1 + P2 : j == 1 ? P2 : j == 2 ? 0 : 0 - P1;
+        if (lane < 4) for (u32 i = 0; i < stripes; i++) v = rnd(v, readLE64(out + 32 * i + 8 * j));
+        const u64 v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+        u32 bad = 0;
+        if (lane == 0) {
+            u64 hh;
+            if (n >= 32) {
+                hh = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+                auto mrg = [&](u64 acc, u64 x) { acc ^= rnd(0, x); return acc * P1 + P4; };
+                hh = mrg(hh, v1); hh = mrg(hh, v2); hh = mrg(hh, v3); hh = mrg(hh, v4);
+            } else hh = P5;
+            hh += (u64)n;
+            const u8* q = out + (stripes << 5); const u8* const end = out + n;
+            while (q + 8 <= end) { hh ^= rnd(0, readLE64(q)); hh = rotl(hh, 27) * P1 + P4; q += 8; }
+            if (q + 4 <= end) { hh ^= (u64)readLE32(q) * P1; hh = rotl(hh, 23) * P2 + P3; q += 4; }
+            while (q < end) { hh ^= (*q) * P5; hh = rotl(hh, 11) * P1; q++; }
+            hh ^= hh >> 33; hh *= P2; hh ^= hh >> 29; hh *= P3; hh ^= hh >> 32;
+            if (fd.srcSize - ip < 4 || (u32)hh != readLE32(fsrc + ip)) bad = 1;
+        }
+        if (uniform(bad)) FAIL(kErrChecksumWrong);
+    }
+    return 0;
+#undef FAIL
+}
+
+__global__ __launch_bounds__(64) void decode_frames_kernel(const u8* __restrict__ src, u64 srcSize, u8* __restrict__ dst, u64 dstCapacity,
+                                                           const FrameDesc* __restrict__ frames, u32 nFrames, u32* __restrict__ frameErr,
+                                                           u8* __restrict__ scratch)
+{
+    __shared__ DecLds L;
+    const u32 f = blockIdx.x, lane = threadIdx.x;
+    if (f >= nFrames) return;
+    const FrameDesc fd = frames[f];
+    if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
+    const u32 err = decode_frame(L, fd, src + fd.srcOff, dst + fd.dstOff, scratch + (u64)f * kScratchPerFrame, lane);
+    if (err && lane == 0) atomicCAS(frameErr, 0u, err);
+}
+
+size_t decode_scratch_per_frame() { return kScratchPerFrame; }
+
+void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream)
+{
+    hipLaunchKernelGGL(frame_walk_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status);
+}
+void launch_decode_frames(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
+                          u8* scratch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(decode_frames_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, scratch);
+}
+
+} // namespace zmi

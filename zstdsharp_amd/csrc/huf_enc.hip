@@ -1,0 +1,460 @@
+// huf_enc.hip — literals section of a block on gfx950.
+//
+//   huf_build_kernel  : one 256-thread workgroup per chunk.  Four waves build the four per-stream byte
+//                       histograms in LDS (HIST_count, U/Hist.cs:67-166); lane 0 then runs the reference's
+//                       code-length construction exactly — HUF_sort / HUF_buildTree / HUF_setMaxHeight /
+//                       HUF_buildCTableFromTree (U/HufCompress.cs:377-823) — and the tree description
+//                       (HUF_writeCTable_wksp + HUF_compressWeights, U/HufCompress.cs:40-235), and takes every
+//                       raw / RLE / compressed decision of ZSTD_compressLiterals (U/ZstdCompressLiterals.cs:86-185)
+//                       and HUF_compress_internal (U/HufCompress.cs:1360-1543).  Because stream sizes follow from
+//                       histogram x code length, the whole literals section is sized before a byte is encoded.
+//   huf_encode_kernel : one 256-thread workgroup per chunk, wave w encodes stream w
+//                       (HUF_compress4X_usingCTable_internal, U/HufCompress.cs:1221-1321): symbols are taken last
+//                       to first, 8 per lane, their codes concatenated in registers, bit offsets come from a wave
+//                       prefix scan, and the lanes OR their bits into an LDS tile that is flushed with coalesced
+//                       dword stores.
+// Given the same literals and sequence count, the bytes produced equal the oracle's (tests/test_parity_entropy).
+#include "zmi_device.h"
+#include "zmi_fse.h"
+
+namespace zmi {
+
+struct Node { u32 count; u16 parent; u8 byte; u8 nbBits; };
+
+struct HufBuildLds {
+    u32 hist[4][256];
+    u32 sample[2][256];
+    u32 count[256];
+    Node nodes[513];
+    u16 rankBase[192], rankCurr[192];
+    u8  nbBits[256];
+    u8  weights[256];
+    // FSE scratch for the weights (alphabet 0..12, tableLog <= 6)
+    u32 wcount[13]; s16 wnorm[13]; u16 wstate[64]; SymTT wtt[13]; u16 wcumul[15]; u8 wsym[64];
+    u32 sampleMax[2];
+    int qsStack[192];
+};
+
+// ---- HUF_sort (U/HufCompress.cs:520-680): bucket sort by count, quicksort inside the log2 buckets ----
+__device__ __forceinline__ u32 huf_get_index(u32 count) { return count < 165 ? count : highbit32(count) + 158; }
+
+__device__ inline void huf_insertion_sort(Node* a, int low, int high)
+{
+    const int size = high - low + 1; a += low;
+    for (int i = 1; i < size; i++) {
+        const Node key = a[i]; int j = i - 1;
+        while (j >= 0 && a[j].count < key.count) { a[j + 1] = a[j]; j--; }
+        a[j + 1] = key;
+    }
+}
+__device__ inline int huf_partition(Node* a, int low, int high)
+{
+    const u32 pivot = a[high].count; int i = low - 1;
+    for (int j = low; j < high; j++) if (a[j].count > pivot) { i++; const Node t = a[i]; a[i] = a[j]; a[j] = t; }
+    { const Node t = a[i + 1]; a[i + 1] = a[high]; a[high] = t; }
+    return i + 1;
+}
+// HUF_simpleQuickSort: a call checks the insertion-sort threshold once, then partitions in a loop, recursing
+// (threshold checked again) into the smaller side and continuing the loop (threshold NOT checked) on the larger.
+// Sub-ranges are disjoint, so an explicit stack of {low, high, isCall} reproduces the result exactly.
+__device__ inline void huf_quick_sort(Node* a, int low0, int high0, int* stack)
+{
+    int sp = 0;
+    stack[sp++] = low0; stack[sp++] = high0; stack[sp++] = 1;
+    while (sp) {
+        const int isCall = stack[--sp]; const int high = stack[--sp]; const int low = stack[--sp];
+        if (isCall && high - low < 8) { huf_insertion_sort(a, low, high); continue; }
+        if (!(low < high)) continue;
+        const int idx = huf_partition(a, low, high);
+        if (idx - low < high - idx) {
+            stack[sp++] = idx + 1; stack[sp++] = high;    stack[sp++] = 0;
+            stack[sp++] = low;     stack[sp++] = idx - 1; stack[sp++] = 1;
+        } else {
+            stack[sp++] = low;     stack[sp++] = idx - 1; stack[sp++] = 0;
+            stack[sp++] = idx + 1; stack[sp++] = high;    stack[sp++] = 1;
+        }
+    }
+}
+
+__device__ inline void huf_sort(HufBuildLds& L, u32 maxSV)
+{
+    Node* huffNode = L.nodes + 1;
+    const u32 maxSV1 = maxSV + 1;
+    for (u32 n = 0; n < 192; n++) { L.rankBase[n] = 0; L.rankCurr[n] = 0; }
+    for (u32 n = 0; n < maxSV1; n++) L.rankBase[huf_get_index(L.count[n])]++;
+    for (u32 n = 191; n > 0; n--) { L.rankBase[n - 1] += L.rankBase[n]; L.rankCurr[n - 1] = L.rankBase[n - 1]; }
+    for (u32 n = 0; n < maxSV1; n++) {
+        const u32 c = L.count[n], r = huf_get_index(c) + 1, pos = L.rankCurr[r]++;
+        huffNode[pos].count = c; huffNode[pos].byte = (u8)n;
+    }
+    for (u32 n = 165; n < 191; n++) {
+        const u32 bucketSize = L.rankCurr[n] - L.rankBase[n], bucketStart = L.rankBase[n];
+        if (bucketSize > 1) huf_quick_sort(huffNode + bucketStart, 0, (int)bucketSize - 1, L.qsStack);
+    }
+}
+
+// ---- HUF_buildTree (U/HufCompress.cs:689-738) ----
+__device__ inline int huf_build_tree(Node* huffNode, u32 maxSV)
+{
+    Node* const huffNode0 = huffNode - 1;
+    int nonNullRank = (int)maxSV, lowS, lowN, nodeNb = 256, nodeRoot;
+    while (huffNode[nonNullRank].count == 0) nonNullRank--;
+    lowS = nonNullRank; nodeRoot = nodeNb + lowS - 1; lowN = nodeNb;
+    huffNode[nodeNb].count = huffNode[lowS].count + huffNode[lowS - 1].count;
+    huffNode[lowS].parent = huffNode[lowS - 1].parent = (u16)nodeNb;
+    nodeNb++; lowS -= 2;
+    for (int n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
+    huffNode0[0].count = 1u << 31;
+    while (nodeNb <= nodeRoot) {
+        const int n1 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        const int n2 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
+        huffNode[nodeNb].count = huffNode[n1].count + huffNode[n2].count;
+        huffNode[n1].parent = huffNode[n2].parent = (u16)nodeNb;
+        nodeNb++;
+    }
+    huffNode[nodeRoot].nbBits = 0;
+    for (int n = nodeRoot - 1; n >= 256; n--) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    for (int n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    return nonNullRank;
+}
+
+// ---- HUF_setMaxHeight (U/HufCompress.cs:377-514) ----
+__device__ inline u32 huf_set_max_height(Node* huffNode, u32 lastNonNull, u32 maxNbBits)
+{
+    const u32 largestBits = huffNode[lastNonNull].nbBits;
+    if (largestBits <= maxNbBits) return largestBits;
+    int totalCost = 0; const u32 baseCost = 1u << (largestBits - maxNbBits); int n = (int)lastNonNull;
+    while (huffNode[n].nbBits > maxNbBits) {
+        totalCost += (int)(baseCost - (1u << (largestBits - huffNode[n].nbBits)));
+        huffNode[n].nbBits = (u8)maxNbBits; n--;
+    }
+    while (huffNode[n].nbBits == maxNbBits) --n;
+    totalCost >>= (largestBits - maxNbBits);
+    const u32 noSymbol = 0xF0F0F0F0; u32 rankLast[14];
+    for (int i = 0; i < 14; i++) rankLast[i] = noSymbol;
+    {
+        u32 currentNbBits = maxNbBits;
+        for (int pos = n; pos >= 0; pos--) {
+            if (huffNode[pos].nbBits >= currentNbBits) continue;
+            currentNbBits = huffNode[pos].nbBits;
+            rankLast[maxNbBits - currentNbBits] = (u32)pos;
+        }
+    }
+    while (totalCost > 0) {
+        u32 nBitsToDecrease = highbit32((u32)totalCost) + 1;
+        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+            const u32 highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
+            if (highPos == noSymbol) continue;
+            if (lowPos == noSymbol) break;
+            const u32 highTotal = huffNode[highPos].count, lowTotal = 2 * huffNode[lowPos].count;
+            if (highTotal <= lowTotal) break;
+        }
+        while (nBitsToDecrease <= 12 && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+        totalCost -= 1 << (nBitsToDecrease - 1);
+        huffNode[rankLast[nBitsToDecrease]].nbBits++;
+        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+        if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+        else {
+            rankLast[nBitsToDecrease]--;
+            if (huffNode[rankLast[nBitsToDecrease]].nbBits != maxNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+        }
+    }
+    while (totalCost < 0) {
+        if (rankLast[1] == noSymbol) {
+            while (huffNode[n].nbBits == maxNbBits) n--;
+            huffNode[n + 1].nbBits--;
+            rankLast[1] = (u32)(n + 1);
+            totalCost++;
+            continue;
+        }
+        huffNode[rankLast[1] + 1].nbBits--;
+        rankLast[1]++;
+        totalCost++;
+    }
+    return maxNbBits;
+}
+
+// ---- HUF_compressWeights (U/HufCompress.cs:40-125); returns bytes written, 0 = not compressible, 1 = single symbol ----
+__device__ inline u32 huf_compress_weights(HufBuildLds& L, u8* dst, u32 wtSize)
+{
+    u32 maxSV = 12;
+    if (wtSize <= 1) return 0;
+    for (u32 s = 0; s <= 12; s++) L.wcount[s] = 0;
+    for (u32 i = 0; i < wtSize; i++) L.wcount[L.weights[i]]++;
+    while (!L.wcount[maxSV]) maxSV--;
+    u32 maxCount = 0;
+    for (u32 s = 0; s <= maxSV; s++) if (L.wcount[s] > maxCount) maxCount = L.wcount[s];
+    if (maxCount == wtSize) return 1;
+    if (maxCount == 1) return 0;
+    const u32 tableLog = fse_optimal_table_log(6, wtSize, maxSV, 2);
+    if (!fse_normalize_count(L.wnorm, tableLog, L.wcount, wtSize, maxSV, 0)) return 0;
+    u8* op = dst;
+    const u32 hs = fse_write_ncount(op, L.wnorm, maxSV, tableLog);
+    if (!hs) return 0;
+    op += hs;
+    fse_build_ctable(L.wstate, L.wtt, L.wnorm, maxSV, tableLog, L.wcumul, L.wsym);
+    // FSE_compress_usingCTable_generic (U/FseCompress.cs:722-820): symbol i uses state (i & 1), last symbol first
+    if (wtSize <= 2) return 0;
+    BitW bw; bw.init(op);
+    u32 st[2];
+    st[(wtSize - 1) & 1] = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 1]);
+    st[(wtSize - 2) & 1] = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 2]);
+    for (u32 i = wtSize - 2; i-- > 0; ) {
+        const SymTT t = L.wtt[L.weights[i]];
+        u32& v = st[i & 1];
+        const u32 nbBitsOut = (v + t.deltaNbBits) >> 16;
+        bw.add(v, nbBitsOut);
+        v = L.wstate[(s32)(v >> nbBitsOut) + t.deltaFindState];
+    }
+    bw.add(st[1], tableLog);
+    bw.add(st[0], tableLog);
+    op = bw.close();
+    return (u32)(op - dst);
+}
+
+__device__ __forceinline__ u32 min_gain(u32 srcSize) { return (srcSize >> 6) + 2; }   // ZSTD_minGain, strategies < btultra
+
+__global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ lits, ChunkMeta* __restrict__ meta,
+                                                        HufTable* __restrict__ tables)
+{
+    __shared__ HufBuildLds L;
+    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    ChunkMeta m = meta[c];
+    const u32 litSize = m.litSize;
+    const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
+    const u32 lhSizeRaw = 1 + (litSize > 31) + (litSize > 4095);
+
+    // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
+    if (litSize <= 63) {
+        if (tid == 0) { m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize; meta[c] = m; }
+        return;
+    }
+    for (u32 i = tid; i < 4 * 256; i += 256) (&L.hist[0][0])[i] = 0;
+    for (u32 i = tid; i < 2 * 256; i += 256) (&L.sample[0][0])[i] = 0;
+    __syncthreads();
+    const u32 seg = (litSize + 3) / 4;
+    {   // wave w counts segment w
+        const u32 s0 = wave * seg, s1 = (s0 + seg < litSize) ? s0 + seg : litSize;
+        for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&L.hist[wave][lit[i]], 1u);
+    }
+    const u32 suspect = (m.nbSeq == 0) || (litSize / m.nbSeq >= 20);
+    const bool doSample = suspect && litSize >= 4096 * 10;
+    if (doSample && wave < 2) {       // HUF_compress_internal's 2 x 4 KiB pre-check (U/HufCompress.cs:1412-1446)
+        const u8* sp = wave == 0 ? lit : lit + litSize - 4096;
+        for (u32 i = lane; i < 4096; i += 64) atomicAdd(&L.sample[wave][sp[i]], 1u);
+    }
+    __syncthreads();
+    {
+        const u32 cnt = L.hist[0][tid] + L.hist[1][tid] + L.hist[2][tid] + L.hist[3][tid];
+        L.count[tid] = cnt;
+        if (doSample && wave < 2) { /* reduce below */ }
+    }
+    if (doSample && wave < 2) {
+        u32 mx = 0;
+        for (u32 i = lane; i < 256; i += 64) { const u32 v = L.sample[wave][i]; mx = v > mx ? v : mx; }
+        mx = wave_max(mx);
+        if (lane == 0) L.sampleMax[wave] = mx;
+    }
+    __syncthreads();
+    if (tid != 0) return;
+
+    // ---------------- serial section: one lane ----------------
+    bool compressed = true; u32 rleByte = 0; bool rle = false;
+    if (doSample && L.sampleMax[0] + L.sampleMax[1] <= ((2 * 4096) >> 7) + 4) compressed = false;
+    u32 maxSV = 255, largest = 0;
+    if (compressed) {
+        while (!L.count[maxSV]) maxSV--;
+        for (u32 s = 0; s <= maxSV; s++) if (L.count[s] > largest) largest = L.count[s];
+        if (largest == litSize) { rle = true; rleByte = lit[0]; compressed = false; }
+        else if (largest <= (litSize >> 7) + 4) compressed = false;
+    }
+    HufTable* T = tables + c;
+    const u32 lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
+    const u32 single = litSize < 256;
+    u32 hSize = 0, huffLog = 0, cLitSize = 0;
+    u32 streamSize[4] = { 0, 0, 0, 0 };
+    if (compressed) {
+        huffLog = fse_optimal_table_log(11, litSize, maxSV, 1);
+        Node* huffNode = L.nodes + 1;
+        for (u32 i = 0; i < 513; i++) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
+        huf_sort(L, maxSV);
+        const int nonNullRank = huf_build_tree(huffNode, maxSV);
+        huffLog = huf_set_max_height(huffNode, (u32)nonNullRank, huffLog);
+        // HUF_buildCTableFromTree
+        u16 nbPerRank[13], valPerRank[13];
+        for (int i = 0; i < 13; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
+        for (int n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+        { u16 mn = 0; for (int n = (int)huffLog; n > 0; n--) { valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
+        for (u32 n = 0; n < 256; n++) L.nbBits[n] = 0;
+        for (u32 n = 0; n <= maxSV; n++) L.nbBits[huffNode[n].byte] = huffNode[n].nbBits;
+        for (u32 n = 0; n < 256; n++) { T->nbBits[n] = L.nbBits[n]; T->code[n] = (n <= maxSV) ? valPerRank[L.nbBits[n]]++ : 0; }
+        T->maxSV = maxSV; T->tableLog = huffLog;
+        // HUF_writeCTable_wksp
+        {
+            u8 bitsToWeight[13]; bitsToWeight[0] = 0;
+            for (u32 n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
+            for (u32 n = 0; n < maxSV; n++) L.weights[n] = bitsToWeight[L.nbBits[n]];
+            const u32 ws = huf_compress_weights(L, T->hdr + 1, maxSV);
+            if (ws > 1 && ws < maxSV / 2) { T->hdr[0] = (u8)ws; hSize = ws + 1; }
+            else if (maxSV > 128) { compressed = false; }     // HUF_writeCTable_wksp fails -> ZSTD_compressLiterals stores raw
+            else {
+                T->hdr[0] = (u8)(128 + (maxSV - 1));
+                L.weights[maxSV] = 0;
+                for (u32 n = 0; n < maxSV; n += 2) T->hdr[(n / 2) + 1] = (u8)((L.weights[n] << 4) + L.weights[n + 1]);
+                hSize = ((maxSV + 1) / 2) + 1;
+            }
+        }
+        if (compressed && hSize + 12 >= litSize) compressed = false;
+    }
+    if (compressed) {
+        // stream sizes = sum(count x nbBits) + end mark, per segment (HUF_compress1X_usingCTable_internal + HUF_closeCStream)
+        if (single) {
+            u64 bits = 0;
+            for (u32 s = 0; s <= maxSV; s++) bits += (u64)L.count[s] * L.nbBits[s];
+            streamSize[0] = (u32)(bits >> 3) + 1;
+            cLitSize = hSize + streamSize[0];
+        } else {
+            if (litSize < 12) compressed = false;
+            cLitSize = hSize + 6;
+            for (u32 w = 0; w < 4 && compressed; w++) {
+                u64 bits = 0;
+                for (u32 s = 0; s <= maxSV; s++) bits += (u64)L.hist[w][s] * L.nbBits[s];
+                streamSize[w] = (u32)(bits >> 3) + 1;
+                if (streamSize[w] > 65535) compressed = false;    // (a zero-length stream cannot occur: the end mark is a byte)
+                cLitSize += streamSize[w];
+            }
+        }
+        if (compressed && cLitSize >= litSize - 1) compressed = false;                     // HUF_compressCTable_internal
+        if (compressed && cLitSize >= litSize - min_gain(litSize)) compressed = false;     // ZSTD_compressLiterals
+    }
+    if (compressed) {
+        m.litMode = kLitCompressed; m.litSingle = single; m.lhSize = lhSize; m.hufHdrSize = hSize;
+        for (int w = 0; w < 4; w++) m.streamSize[w] = streamSize[w];
+        m.litSectionSize = lhSize + cLitSize;
+    } else if (rle) {
+        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = rleByte;
+    } else {
+        m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize;
+    }
+    meta[c] = m;
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kSymPerLane = 8;
+constexpr u32 kTileSyms   = 64 * kSymPerLane;             // 512 symbols per wave step, <= 5632 bits
+constexpr u32 kTileWords  = (kTileSyms * 11 + 31) / 32 + 2;
+
+struct HufEncLds {
+    u32 ct[256];                       // code | nbBits << 16
+    u32 tile[4][kTileWords];
+};
+
+__global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ lits, const ChunkMeta* __restrict__ meta,
+                                                         const HufTable* __restrict__ tables, u8* __restrict__ slots)
+{
+    __shared__ HufEncLds L;
+    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const ChunkMeta m = meta[c];
+    const u32 litSize = m.litSize;
+    const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
+    u8* __restrict__ body = slots + (u64)c * kSlotStride + m.fhSize + 3;      // block body starts after frame + block header
+
+    if (m.litMode != kLitCompressed) {
+        // ZSTD_noCompressLiterals / ZSTD_compressRleLiteralsBlock (U/ZstdCompressLiterals.cs:8-83)
+        const u32 type = m.litMode == kLitRle ? 1u : 0u;
+        if (tid == 0) {
+            switch (m.lhSize) {
+            case 1: body[0] = (u8)(type + (litSize << 3)); break;
+            case 2: writeLE16(body, type + (1u << 2) + (litSize << 4)); break;
+            default: writeLE24(body, type + (3u << 2) + (litSize << 4)); break;
+            }
+            if (type == 1) body[m.lhSize] = (u8)m.pad[0];
+        }
+        if (type == 0) for (u32 i = tid; i < litSize; i += 256) body[m.lhSize + i] = lit[i];
+        return;
+    }
+    const HufTable* __restrict__ T = tables + c;
+    L.ct[tid] = (u32)T->code[tid] | ((u32)T->nbBits[tid] << 16);
+    if (tid == 0) {
+        const u32 cLitSize = m.litSectionSize - m.lhSize;
+        switch (m.lhSize) {       // ZSTD_compressLiterals header (U/ZstdCompressLiterals.cs:150-182)
+        case 3: writeLE24(body, 2u + ((m.litSingle ? 0u : 1u) << 2) + (litSize << 4) + (cLitSize << 14)); break;
+        case 4: writeLE32(body, 2u + (2u << 2) + (litSize << 4) + (cLitSize << 18)); break;
+        default: writeLE32(body, 2u + (3u << 2) + (litSize << 4) + (cLitSize << 22)); body[4] = (u8)(cLitSize >> 10); break;
+        }
+    }
+    for (u32 i = tid; i < m.hufHdrSize; i += 256) body[m.lhSize + i] = T->hdr[i];
+    u8* payload = body + m.lhSize + m.hufHdrSize;
+    if (!m.litSingle && tid < 3) writeLE16(payload + 2 * tid, m.streamSize[tid]);       // jump table
+    __syncthreads();
+
+    const u32 nStreams = m.litSingle ? 1 : 4;
+    if (wave >= nStreams) return;
+    const u32 seg = m.litSingle ? litSize : (litSize + 3) / 4;
+    const u32 s0 = wave * seg;
+    const u32 len = (wave == nStreams - 1) ? litSize - s0 : seg;
+    u8* out = payload + (m.litSingle ? 0 : 6);
+    for (u32 w = 0; w < wave; w++) out += m.streamSize[w];
+    const u8* __restrict__ sym = lit + s0;
+    u32* tile = L.tile[wave];
+
+    u32 carry = 0, carryBits = 0;        // bits of a partially filled dword carried into the next tile
+    u32 outWords = 0;                    // dwords already flushed to `out`
+    for (u32 k0 = 0; k0 < len; k0 += kTileSyms) {
+        for (u32 i = lane; i < kTileWords; i += 64) tile[i] = 0;
+        // lane handles reversed indices k0 + lane*8 .. +7  ->  source bytes len-1-k, descending
+        const u32 kb = k0 + lane * kSymPerLane;
+        u64 lo = 0, hi = 0; u32 nb = 0;
+#pragma unroll
+        for (u32 j = 0; j < kSymPerLane; j++) {
+            const u32 k = kb + j;
+            if (k < len) {
+                const u32 e = L.ct[sym[len - 1 - k]];
+                const u64 code = e & 0xFFFF; const u32 b = e >> 16;
+                if (nb < 64) { lo |= code << nb; if (nb + b > 64) hi |= code >> (64 - nb); }
+                else hi |= code << (nb - 64);
+                nb += b;
+            }
+        }
+        const u32 incl = wave_scan_incl(nb);
+        const u32 tileBits = read_lane(incl, 63);
+        const u32 bitOff = carryBits + incl - nb;
+        if (nb) {
+            const u32 w0 = bitOff >> 5, sh = bitOff & 31;
+            // up to 88 bits shifted by <32 -> spans at most 4 dwords
+            const u64 a0 = lo << sh;
+            const u64 a1 = sh ? ((lo >> (64 - sh)) | (hi << sh)) : hi;
+            atomicOr(&tile[w0], (u32)a0);
+            if ((u32)(a0 >> 32)) atomicOr(&tile[w0 + 1], (u32)(a0 >> 32));
+            if ((u32)a1) atomicOr(&tile[w0 + 2], (u32)a1);
+            if ((u32)(a1 >> 32)) atomicOr(&tile[w0 + 3], (u32)(a1 >> 32));
+        }
+        if (lane == 0 && carryBits) atomicOr(&tile[0], carry);
+        const u32 total = carryBits + tileBits;
+        const u32 fullWords = total >> 5;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (u32 i = lane; i < fullWords; i += 64) *(u32u*)(out + 4 * (outWords + i)) = tile[i];
+        carry = tile[fullWords]; carryBits = total & 31;       // every lane reads the same LDS word
+        outWords += fullWords;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    }
+    if (lane == 0) {       // end mark + tail bytes (HUF_closeCStream, U/HufCompress.cs:964-979)
+        u32 v = carry | (1u << carryBits);
+        const u32 nbytes = (carryBits + 1 + 7) >> 3;
+        u8* p = out + 4 * outWords;
+        for (u32 i = 0; i < nbytes; i++) { p[i] = (u8)v; v >>= 8; }
+    }
+}
+
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u32 nChunks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(huf_build_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables);
+}
+void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream)
+{
+    hipLaunchKernelGGL(huf_encode_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables, slots);
+}
+
+} // namespace zmi

@@ -1,0 +1,188 @@
+// seq_enc.hip — sequences section + block/frame finalisation on gfx950.
+//
+// One wave per chunk, four chunks per 256-thread workgroup.  The 64 lanes build the LL/OF/ML code histograms in
+// LDS (ZSTD_seqToCodes U/ZstdCompress.cs:3069-3098 + HIST_countFast); lane 0 then runs the block's serial
+// section exactly as the reference does — ZSTD_selectEncodingType's strategy<lazy heuristic
+// (U/ZstdCompressSequences.cs:400-469), ZSTD_buildCTable (:471-582), and the three interleaved tANS state chains
+// of ZSTD_encodeSequences_body (:585-704) — writing straight into the chunk's output slot behind the literals
+// section that huf_build already sized.  The same lane then applies ZSTD_entropyCompressSeqStore's
+// "compressed enough?" rule (U/ZstdCompress.cs:3357-3392) and writes the block header (U/ZstdCompress.cs:4792)
+// and the single-segment frame header (U/ZstdCompress.cs:4817-4929).
+// The state chains are serial per block by construction (U/Fse.cs:41-49); the GPU gets its parallelism from the
+// 16 384 independent chunks per GiB, which is why this kernel keeps LDS small and occupancy at 32 waves/CU.
+#include "zmi_device.h"
+#include "zmi_fse.h"
+
+namespace zmi {
+
+__constant__ u8 cLL_Code[64] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,16,17,17,18,18,19,19,20,20,20,20,21,21,21,21,
+    22,22,22,22,22,22,22,22,23,23,23,23,23,23,23,23,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24,24 };
+__constant__ u8 cML_Code[128] = { 0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,30,31,
+    32,32,33,33,34,34,35,35,36,36,36,36,37,37,37,37,38,38,38,38,38,38,38,38,39,39,39,39,39,39,39,39,
+    40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,40,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,41,
+    42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42,42 };
+__constant__ u8 cLL_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
+__constant__ u8 cML_bits[53] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,
+                                 1,1,1,1,2,2,3,3,4,4,5,7,8,9,10,11,12,13,14,15,16 };
+__constant__ s16 cLL_defaultNorm[36] = { 4,3,2,2,2,2,2,2,2,2,2,2,2,1,1,1,2,2,2,2,2,2,2,2,2,3,2,1,1,1,1,1,-1,-1,-1,-1 };
+__constant__ s16 cML_defaultNorm[53] = { 1,4,3,2,2,2,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,
+                                         1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1,-1,-1 };
+__constant__ s16 cOF_defaultNorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1,1,1,1,1,-1,-1,-1,-1,-1 };
+
+__device__ __forceinline__ u32 ll_code(u32 ll) { return ll > 63 ? highbit32(ll) + 19 : cLL_Code[ll]; }
+__device__ __forceinline__ u32 ml_code(u32 ml) { return ml > 127 ? highbit32(ml) + 36 : cML_Code[ml]; }
+
+struct SeqWaveLds {
+    u32 count[3][64];                   // LL, OF, ML code histograms
+    u16 llState[512]; u16 mlState[512]; u16 ofState[256];
+    SymTT llTT[36]; SymTT mlTT[53]; SymTT ofTT[32];
+    s16 norm[64]; u16 cumul[66]; u8 tableSymbol[512];
+};
+
+struct SeqTable { const u16* state; const SymTT* tt; u32 tableLog; };
+
+// ZSTD_selectEncodingType + ZSTD_buildCTable for one of LL/OF/ML; returns bytes written to `op`
+__device__ inline u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count, u32 maxPossible, u32 FSELog, u32 nbSeq, u32 lastCode,
+                                      const s16* defaultNorm, u32 defaultNormLog, u32 defaultMax, bool defaultAllowedByMax,
+                                      u32 strategy, u16* stateTable, SymTT* tt, u32* typeOut, u32* tableLogOut, u32* lastCountSize)
+{
+    u32 max = maxPossible, mostFrequent = 0;
+    while (!count[max]) max--;
+    for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
+    const bool isDefaultAllowed = defaultAllowedByMax ? (max <= defaultMax) : true;
+    u32 type;
+    if (mostFrequent == nbSeq) type = (isDefaultAllowed && nbSeq <= 2) ? 0 : 1;
+    else {
+        type = 2;
+        if (isDefaultAllowed) {
+            const u32 mult = 10 - strategy, dynamicFse_nbSeq_min = ((1u << defaultNormLog) * mult) >> 3;
+            if (nbSeq < dynamicFse_nbSeq_min || mostFrequent < (nbSeq >> (defaultNormLog - 1))) type = 0;
+        }
+    }
+    *typeOut = type;
+    if (type == 1) {            // set_rle: FSE_buildCTable_rle
+        stateTable[0] = 0; stateTable[1] = 0;
+        tt[max].deltaNbBits = 0; tt[max].deltaFindState = 0;
+        *tableLogOut = 0;
+        op[0] = (u8)lastCode;   // the reference writes codeTable[0]; every code is equal here
+        return 1;
+    }
+    if (type == 0) {            // set_basic
+        for (u32 s = 0; s <= defaultMax; s++) W.norm[s] = defaultNorm[s];
+        fse_build_ctable(stateTable, tt, W.norm, defaultMax, defaultNormLog, W.cumul, W.tableSymbol);
+        *tableLogOut = defaultNormLog;
+        return 0;
+    }
+    {                           // set_compressed
+        u32 nbSeq_1 = nbSeq;
+        const u32 tableLog = fse_optimal_table_log(FSELog, nbSeq, max, 2);
+        if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
+        fse_normalize_count(W.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048);
+        const u32 n = fse_write_ncount(op, W.norm, max, tableLog);
+        fse_build_ctable(stateTable, tt, W.norm, max, tableLog, W.cumul, W.tableSymbol);
+        *tableLogOut = tableLog;
+        *lastCountSize = n;
+        return n;
+    }
+}
+
+__global__ __launch_bounds__(256) void seq_encode_kernel(const Seq* __restrict__ seqs, ChunkMeta* __restrict__ meta,
+                                                         u8* __restrict__ slots, u32 nChunks, u32 strategy, u32 checksumFlag)
+{
+    __shared__ SeqWaveLds Ws[4];
+    const u32 lane = lane_id(), wave = wave_id();
+    const u32 c = blockIdx.x * 4 + wave;
+    if (c >= nChunks) return;
+    SeqWaveLds& W = Ws[wave];
+    ChunkMeta m = meta[c];
+    const u32 nbSeq = m.nbSeq, n = m.srcSize;
+    const Seq* __restrict__ sq = seqs + (u64)c * kMaxSeq;
+    u8* const slot = slots + (u64)c * kSlotStride;
+    u8* const body = slot + m.fhSize + 3;
+
+    for (u32 i = lane; i < 3 * 64; i += 64) (&W.count[0][0])[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    for (u32 i = lane; i < nbSeq; i += 64) {
+        const Seq s = sq[i];
+        atomicAdd(&W.count[0][ll_code(s.litLength)], 1u);
+        atomicAdd(&W.count[1][highbit32(s.offBase)], 1u);
+        atomicAdd(&W.count[2][ml_code(s.mlBase)], 1u);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    if (lane != 0) return;
+
+    // ---------------- serial section: one lane ----------------
+    u8* op = body + m.litSectionSize;
+    bool giveUp = n < 7;                 // ZSTD_buildSeqStore: blocks under MIN_CBLOCK_SIZE+header are never compressed
+    if (!giveUp) {
+        if (nbSeq < 128) *op++ = (u8)nbSeq;
+        else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
+        else { op[0] = 0xFF; writeLE16(op + 1, nbSeq - 0x7F00); op += 3; }
+    }
+    if (!giveUp && nbSeq) {
+        u8* const seqHead = op++;
+        const Seq last = sq[nbSeq - 1];
+        const u32 lastLL = ll_code(last.litLength), lastOF = highbit32(last.offBase), lastML = ml_code(last.mlBase);
+        u32 LLtype, OFtype, MLtype, llLog, ofLog, mlLog, lastCountSize = 0;
+        op += build_seq_table(W, op, W.count[0], 35, 9, nbSeq, lastLL, cLL_defaultNorm, 6, 35, false, strategy, W.llState, W.llTT, &LLtype, &llLog, &lastCountSize);
+        op += build_seq_table(W, op, W.count[1], 31, 8, nbSeq, lastOF, cOF_defaultNorm, 5, 28, true,  strategy, W.ofState, W.ofTT, &OFtype, &ofLog, &lastCountSize);
+        op += build_seq_table(W, op, W.count[2], 52, 9, nbSeq, lastML, cML_defaultNorm, 6, 52, false, strategy, W.mlState, W.mlTT, &MLtype, &mlLog, &lastCountSize);
+        // lastCountSize must be the size of the LAST compressed table description (U/ZstdCompress.cs:3196-3224)
+        *seqHead = (u8)((LLtype << 6) + (OFtype << 4) + (MLtype << 2));
+
+        // ZSTD_encodeSequences_body
+        BitW bw; bw.init(op);
+        u32 sLL = fse_init_state2(W.llState, W.llTT, lastLL);
+        u32 sOF = fse_init_state2(W.ofState, W.ofTT, lastOF);
+        u32 sML = fse_init_state2(W.mlState, W.mlTT, lastML);
+        bw.add(last.litLength, cLL_bits[lastLL]);
+        bw.add(last.mlBase, cML_bits[lastML]);
+        bw.add(last.offBase, lastOF);
+        for (u32 i = nbSeq - 1; i-- > 0; ) {
+            const Seq s = sq[i];
+            const u32 ll = ll_code(s.litLength), of = highbit32(s.offBase), ml = ml_code(s.mlBase);
+            { const SymTT t = W.ofTT[of]; const u32 nb = (sOF + t.deltaNbBits) >> 16; bw.add(sOF, nb); sOF = W.ofState[(s32)(sOF >> nb) + t.deltaFindState]; }
+            { const SymTT t = W.mlTT[ml]; const u32 nb = (sML + t.deltaNbBits) >> 16; bw.add(sML, nb); sML = W.mlState[(s32)(sML >> nb) + t.deltaFindState]; }
+            { const SymTT t = W.llTT[ll]; const u32 nb = (sLL + t.deltaNbBits) >> 16; bw.add(sLL, nb); sLL = W.llState[(s32)(sLL >> nb) + t.deltaFindState]; }
+            bw.add(s.litLength, cLL_bits[ll]);
+            bw.add(s.mlBase, cML_bits[ml]);
+            bw.add(s.offBase, of);
+        }
+        bw.add(sML, mlLog); bw.add(sOF, ofLog); bw.add(sLL, llLog);
+        u8* const end = bw.close();
+        const u32 bitstreamSize = (u32)(end - op);
+        op = end;
+        if (lastCountSize && lastCountSize + bitstreamSize < 4) giveUp = true;      // 1.3.4 decoder quirk (:3346-3350)
+    }
+    u32 cSize = (u32)(op - body);
+    if (!giveUp && cSize >= n - ((n >> 6) + 2)) giveUp = true;                      // ZSTD_minGain
+
+    // ---- frame header (single segment, content size known) ----
+    {
+        const u32 fcsCode = (n >= 256) + (n >= 65536 + 256);
+        writeLE32(slot, 0xFD2FB528u);
+        slot[4] = (u8)(((checksumFlag ? 1u : 0u) << 2) + (1u << 5) + (fcsCode << 6));
+        if (fcsCode == 0) slot[5] = (u8)n;
+        else if (fcsCode == 1) writeLE16(slot + 5, n - 256);
+        else writeLE32(slot + 5, n);
+    }
+    u8* const bh = slot + m.fhSize;
+    if (giveUp) {            // ZSTD_noCompressBlock: the gather kernel copies the n source bytes behind this header
+        writeLE24(bh, 1u + (0u << 1) + (n << 3));
+        m.blockType = 0; m.bodySize = 0; cSize = n;
+    } else {
+        writeLE24(bh, 1u + (2u << 1) + (cSize << 3));
+        m.blockType = 2; m.bodySize = cSize;
+    }
+    m.outSize = m.fhSize + 3 + cSize + (checksumFlag ? 4 : 0);
+    meta[c] = m;
+}
+
+void launch_seq_encode(const Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag);
+}
+
+} // namespace zmi

@@ -1,0 +1,605 @@
+// zstd_mi355x.hip — host side of libzstd_mi355x.so: contexts, parameters, error names, HBM workspaces and the
+// launch sequences of the compress / decompress pipelines.  The C ABI is declared in include/zstd_mi355x.h.
+//
+// There is no CPU codec in this library: without a usable gfx950 device every compress/decompress call returns
+// ZSTD_error_GENERIC... no — it returns memory_allocation from context creation or init_missing from the call, loudly.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+#include <stdio.h>
+#include <vector>
+#include <mutex>
+#include "zmi_common.h"
+#include "../../include/zstd_mi355x.h"
+
+namespace zmi {
+// kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
+void launch_lz_fast(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream);
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u32 nChunks, hipStream_t stream);
+void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
+void launch_seq_encode(const Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, hipStream_t stream);
+void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
+void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
+                   u32 nChunks, hipStream_t stream);
+void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, hipStream_t stream);
+// decoder
+struct DecodeWork;
+size_t decode_workspace_bytes(u32 maxFrames);
+void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total lo/hi*/, hipStream_t stream);
+void launch_decode_frames(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
+                          u8* scratch, hipStream_t stream);
+size_t decode_scratch_per_frame();
+}
+
+using namespace zmi;
+
+#define ZERR(code) ((size_t)0 - (size_t)(code))
+static inline bool isErr(size_t c) { return c > ZERR(kErrMaxCode); }
+
+namespace {
+
+constexpr int kMaxStages = 12;
+
+struct DevBuf {
+    void* p = nullptr; size_t cap = 0;
+    bool ensure(size_t n)
+    {
+        if (n <= cap) return true;
+        if (p) { (void)hipFree(p); p = nullptr; cap = 0; }
+        size_t want = n + (n >> 3) + 4096;
+        if (hipMalloc(&p, want) != hipSuccess) { p = nullptr; if (hipMalloc(&p, n) != hipSuccess) { p = nullptr; return false; } want = n; }
+        cap = want; return true;
+    }
+    void release() { if (p) (void)hipFree(p); p = nullptr; cap = 0; }
+};
+
+struct StageTimer {
+    bool enabled = false;
+    hipEvent_t ev[kMaxStages + 1] = {};
+    const char* names[kMaxStages] = {};
+    float ms[kMaxStages] = {};
+    int n = 0; bool created = false;
+    void begin(hipStream_t s) { n = 0; if (!enabled) return; if (!created) { for (auto& e : ev) (void)hipEventCreate(&e); created = true; } (void)hipEventRecord(ev[0], s); }
+    void mark(const char* name, hipStream_t s) { if (!enabled || n >= kMaxStages) return; names[n] = name; (void)hipEventRecord(ev[n + 1], s); n++; }
+    void finish() { if (!enabled) return; for (int i = 0; i < n; i++) { float t = 0; (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]); ms[i] = t; } }
+    void accumulate(StageTimer& into) { (void)into; }
+    void destroy() { if (created) for (auto& e : ev) (void)hipEventDestroy(e); created = false; }
+};
+
+bool is_device_ptr(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
+}
+
+int device_count()
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+
+} // namespace
+
+// ======================================================================================================
+struct ZSTD_CCtx_s {
+    int level = 3;              // ZSTD_CLEVEL_DEFAULT
+    int checksumFlag = 0, contentSizeFlag = 1, dictIDFlag = 1;
+    int windowLog = 0, hashLog = 0, chainLog = 0, searchLog = 0, minMatch = 0, targetLength = 0, strategy = 0;
+    int device = 0; bool deviceOk = false;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    DevBuf seqs, lits, meta, tables, slots, offsets, total, stageSrc, stageDst;
+    u32 lastChunks = 0;         // chunks of the last pass (debug hook)
+    StageTimer timer;
+    float stageMs[kMaxStages] = {}; const char* stageNames[kMaxStages] = {}; int nStages = 0;
+};
+
+struct ZSTD_DCtx_s {
+    int windowLogMax = 27;
+    int device = 0; bool deviceOk = false;
+    hipStream_t ownStream = nullptr, stream = nullptr;
+    DevBuf frames, status, frameErr, scratch, stageSrc, stageDst;
+    StageTimer timer;
+};
+
+static const u32 kPassChunks = 16384;       // 1 GiB of input per pass; bounds the HBM workspace to ~4.2 GiB
+
+static size_t cctx_bind(ZSTD_CCtx* c)
+{
+    if (!c) return ZERR(kErrGeneric);
+    if (!c->deviceOk) {
+        if (device_count() <= c->device) return ZERR(kErrInitMissing);       // no gfx950 device: fail loudly, never fall back
+        if (hipSetDevice(c->device) != hipSuccess) return ZERR(kErrInitMissing);
+        if (!c->ownStream && hipStreamCreateWithFlags(&c->ownStream, hipStreamNonBlocking) != hipSuccess) return ZERR(kErrMemoryAllocation);
+        if (!c->stream) c->stream = c->ownStream;
+        c->deviceOk = true;
+    } else if (hipSetDevice(c->device) != hipSuccess) return ZERR(kErrInitMissing);
+    return 0;
+}
+static size_t dctx_bind(ZSTD_DCtx* d)
+{
+    if (!d) return ZERR(kErrGeneric);
+    if (!d->deviceOk) {
+        if (device_count() <= d->device) return ZERR(kErrInitMissing);
+        if (hipSetDevice(d->device) != hipSuccess) return ZERR(kErrInitMissing);
+        if (!d->ownStream && hipStreamCreateWithFlags(&d->ownStream, hipStreamNonBlocking) != hipSuccess) return ZERR(kErrMemoryAllocation);
+        if (!d->stream) d->stream = d->ownStream;
+        d->deviceOk = true;
+    } else if (hipSetDevice(d->device) != hipSuccess) return ZERR(kErrInitMissing);
+    return 0;
+}
+
+static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
+{
+    return c->seqs.ensure((size_t)nChunks * kMaxSeq * sizeof(Seq)) && c->lits.ensure((size_t)nChunks * kChunkSize + 64) &&
+           c->meta.ensure((size_t)nChunks * sizeof(ChunkMeta)) && c->tables.ensure((size_t)nChunks * sizeof(HufTable)) &&
+           c->slots.ensure((size_t)nChunks * kSlotStride + 64) && c->offsets.ensure((size_t)nChunks * sizeof(u64)) &&
+           c->total.ensure(64);
+}
+
+// strategy the entropy stage should assume for a level (U/Clevels.cs rows for <= 128 KiB inputs)
+static u32 strategy_for_level(int level) { (void)level; return 1; /* ZSTD_fast: the only match finder of this round */ }
+
+// the compress pipeline over device-resident buffers
+static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+{
+    hipStream_t s = c->stream;
+    if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
+        u8 f[13]; size_t n = 0;
+        f[n++] = 0x28; f[n++] = 0xB5; f[n++] = 0x2F; f[n++] = 0xFD;
+        f[n++] = (u8)((c->checksumFlag ? 4 : 0) | 0x20); f[n++] = 0;
+        f[n++] = 1; f[n++] = 0; f[n++] = 0;
+        if (c->checksumFlag) { f[n++] = 0x99; f[n++] = 0xE9; f[n++] = 0xD8; f[n++] = 0x51; }   // XXH64("") low 32 bits = 0x51D8E999
+        if (dstCapacity < n) return ZERR(kErrDstSizeTooSmall);
+        if (hipMemcpyAsync(d_dst, f, n, hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+        (void)hipStreamSynchronize(s);
+        return n;
+    }
+    const u64 totalChunks = (srcSize + kChunkSize - 1) / kChunkSize;
+    const u32 passChunks = (u32)(totalChunks < kPassChunks ? totalChunks : kPassChunks);
+    if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
+    const u32 strategy = strategy_for_level(c->level);
+    size_t produced = 0;
+    c->timer.enabled = c->timer.enabled;   // keep
+    bool first = true;
+    for (u64 c0 = 0; c0 < totalChunks; c0 += passChunks) {
+        const u32 nChunks = (u32)((totalChunks - c0) < passChunks ? (totalChunks - c0) : passChunks);
+        const u8* src = d_src + c0 * kChunkSize;
+        const u64 n = (srcSize - c0 * kChunkSize) < (u64)nChunks * kChunkSize ? (srcSize - c0 * kChunkSize) : (u64)nChunks * kChunkSize;
+        Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
+        HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
+        if (first) c->timer.begin(s);
+        launch_lz_fast(src, n, nChunks, seqs, lits, meta, s);                       if (first) c->timer.mark("lz_fast", s);
+        launch_huf_build(lits, meta, tables, nChunks, s);                          if (first) c->timer.mark("huf_build", s);
+        launch_huf_encode(lits, meta, tables, slots, nChunks, s);                  if (first) c->timer.mark("huf_encode", s);
+        if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, s);             if (first) c->timer.mark("xxh64", s); }
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, s);   if (first) c->timer.mark("seq_encode", s);
+        launch_scan_sizes(meta, nChunks, offsets, total, s);                       if (first) c->timer.mark("scan", s);
+        const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
+        launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, s);      if (first) c->timer.mark("gather", s);
+        u64 passTotal = 0;
+        if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        if (first) { c->timer.finish(); c->nStages = c->timer.n; for (int i = 0; i < c->timer.n; i++) { c->stageMs[i] = c->timer.ms[i]; c->stageNames[i] = c->timer.names[i]; } }
+        else if (c->timer.enabled) { /* later passes are not re-timed */ }
+        first = false;
+        if (passTotal > room) return ZERR(kErrDstSizeTooSmall);
+        produced += (size_t)passTotal;
+        c->lastChunks = nChunks;
+    }
+    return produced;
+}
+
+// ======================================================================================================
+extern "C" {
+
+ZSTD_CCtx* ZSTD_createCCtx(void) { return new (std::nothrow) ZSTD_CCtx_s(); }
+
+size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
+{
+    if (!c) return 0;
+    if (c->deviceOk) {
+        (void)hipSetDevice(c->device);
+        if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
+        c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release();
+        c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release();
+        c->timer.destroy();
+        if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
+    }
+    delete c;
+    return 0;
+}
+
+int ZSTD_minCLevel(void) { return -(1 << 17); }
+int ZSTD_maxCLevel(void) { return 22; }
+int ZSTD_defaultCLevel(void) { return 3; }
+
+size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
+{
+    if (!c) return ZERR(kErrGeneric);
+    switch (param) {
+    case ZSTD_c_compressionLevel:           // clamped, 0 means default (U/ZstdCompress.cs:886-905)
+        if (value < ZSTD_minCLevel()) value = ZSTD_minCLevel();
+        if (value > ZSTD_maxCLevel()) value = ZSTD_maxCLevel();
+        c->level = value == 0 ? 3 : value;
+        return (size_t)c->level;
+    case ZSTD_c_checksumFlag:    if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound); c->checksumFlag = value; return (size_t)value;
+    case ZSTD_c_contentSizeFlag: if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound);
+                                 if (value == 0) return ZERR(kErrParameterUnsupported);   /* the GPU framing needs sized frames */
+                                 c->contentSizeFlag = value; return (size_t)value;
+    case ZSTD_c_dictIDFlag:      if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound); c->dictIDFlag = value; return (size_t)value;
+    case ZSTD_c_nbWorkers:       if (value != 0) return ZERR(kErrParameterUnsupported); return 0;   /* as U/ZstdCompress.cs:1064-1072 */
+    case ZSTD_c_windowLog:       if (value != 0 && (value < 10 || value > 31)) return ZERR(kErrParameterOutOfBound);
+                                 if (value != 0 && value < (int)kChunkLog) return ZERR(kErrParameterUnsupported);   /* frames are 64 KiB single-segment */
+                                 c->windowLog = value; return (size_t)value;
+    case ZSTD_c_hashLog: case ZSTD_c_chainLog: case ZSTD_c_searchLog: case ZSTD_c_minMatch: case ZSTD_c_targetLength: case ZSTD_c_strategy:
+        if (value != 0) return ZERR(kErrParameterUnsupported);      /* match-finder geometry is fixed by the kernels */
+        return 0;
+    default: return ZERR(kErrParameterUnsupported);
+    }
+}
+
+size_t ZSTD_CCtx_getParameter(const ZSTD_CCtx* c, int param, int* value)
+{
+    if (!c || !value) return ZERR(kErrGeneric);
+    switch (param) {
+    case ZSTD_c_compressionLevel: *value = c->level; return 0;
+    case ZSTD_c_checksumFlag: *value = c->checksumFlag; return 0;
+    case ZSTD_c_contentSizeFlag: *value = c->contentSizeFlag; return 0;
+    case ZSTD_c_dictIDFlag: *value = c->dictIDFlag; return 0;
+    case ZSTD_c_nbWorkers: *value = 0; return 0;
+    case ZSTD_c_windowLog: *value = c->windowLog; return 0;
+    case ZSTD_c_hashLog: case ZSTD_c_chainLog: case ZSTD_c_searchLog: case ZSTD_c_minMatch: case ZSTD_c_targetLength: case ZSTD_c_strategy:
+        *value = 0; return 0;
+    default: return ZERR(kErrParameterUnsupported);
+    }
+}
+
+size_t ZSTD_CCtx_loadDictionary(ZSTD_CCtx* c, const void* dict, size_t dictSize)
+{
+    if (!c) return ZERR(kErrGeneric);
+    if (dict == nullptr || dictSize == 0) return 0;          /* "no dictionary" */
+    return ZERR(kErrParameterUnsupported);
+}
+
+size_t ZSTD_compressBound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
+
+size_t ZSTDMI_compressDevice(ZSTD_CCtx* c, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
+{
+    size_t e = cctx_bind(c); if (isErr(e)) return e;
+    if (srcSize && !d_src) return ZERR(kErrSrcSizeWrong);
+    if (!d_dst && dstCapacity) return ZERR(kErrDstBufferNull);
+    if (!d_dst) return ZERR(kErrDstSizeTooSmall);
+    return compress_device(c, (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
+}
+
+size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    size_t e = cctx_bind(c); if (isErr(e)) return e;
+    if (srcSize && !src) return ZERR(kErrSrcSizeWrong);
+    if (!dst) return ZERR(kErrDstSizeTooSmall);
+    const bool srcDev = srcSize ? is_device_ptr(src) : true, dstDev = is_device_ptr(dst);
+    const u8* d_src = (const u8*)src; u8* d_dst = (u8*)dst;
+    size_t devCap = dstCapacity;
+    if (!srcDev) {
+        if (!c->stageSrc.ensure(srcSize + 64)) return ZERR(kErrMemoryAllocation);
+        if (hipMemcpyAsync(c->stageSrc.p, src, srcSize, hipMemcpyHostToDevice, c->stream) != hipSuccess) return ZERR(kErrGeneric);
+        d_src = (const u8*)c->stageSrc.p;
+    }
+    if (!dstDev) {
+        const size_t worst = ZSTD_compressBound(srcSize) + 32;
+        devCap = dstCapacity < worst ? dstCapacity : worst;
+        if (!c->stageDst.ensure(devCap + 64)) return ZERR(kErrMemoryAllocation);
+        d_dst = (u8*)c->stageDst.p;
+    }
+    const size_t r = compress_device(c, d_dst, devCap, d_src, srcSize);
+    if (isErr(r)) return r;
+    if (!dstDev) {
+        if (hipMemcpyAsync(dst, d_dst, r, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(c->stream) != hipSuccess) return ZERR(kErrGeneric);
+    }
+    return r;
+}
+
+size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
+{
+    if (!c) return ZERR(kErrGeneric);
+    // ZSTD_compressCCtx = compress_usingDict(NULL) with this level and default frame parameters (U/ZstdCompress.cs:5772-5776)
+    const int savedLevel = c->level, savedChk = c->checksumFlag;
+    c->level = level == 0 ? 3 : level; c->checksumFlag = 0;
+    const size_t r = ZSTD_compress2(c, dst, dstCapacity, src, srcSize);
+    c->level = savedLevel; c->checksumFlag = savedChk;
+    return r;
+}
+
+// ---------------- decompression ----------------
+ZSTD_DCtx* ZSTD_createDCtx(void) { return new (std::nothrow) ZSTD_DCtx_s(); }
+size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
+{
+    if (!d) return 0;
+    if (d->deviceOk) {
+        (void)hipSetDevice(d->device);
+        if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
+        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->stageSrc.release(); d->stageDst.release();
+        d->timer.destroy();
+        if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
+    }
+    delete d;
+    return 0;
+}
+size_t ZSTD_DCtx_setParameter(ZSTD_DCtx* d, int param, int value)
+{
+    if (!d) return ZERR(kErrGeneric);
+    if (param == ZSTD_d_windowLogMax) { if (value != 0 && (value < 10 || value > 31)) return ZERR(kErrParameterOutOfBound); d->windowLogMax = value ? value : 27; return 0; }
+    return ZERR(kErrParameterUnsupported);
+}
+size_t ZSTD_DCtx_getParameter(ZSTD_DCtx* d, int param, int* value)
+{
+    if (!d || !value) return ZERR(kErrGeneric);
+    if (param == ZSTD_d_windowLogMax) { *value = d->windowLogMax; return 0; }
+    return ZERR(kErrParameterUnsupported);
+}
+size_t ZSTD_DCtx_loadDictionary(ZSTD_DCtx* d, const void* dict, size_t dictSize)
+{
+    if (!d) return ZERR(kErrGeneric);
+    if (dict == nullptr || dictSize == 0) return 0;
+    return ZERR(kErrParameterUnsupported);
+}
+
+// Host-side header walk for host buffers (ZSTD_findFrameSizeInfo, U/ZstdDecompress.cs:877-951): headers only, no payload.
+static size_t host_frame_size_info(const u8* src, size_t srcSize, unsigned long long* bound)
+{
+    auto rd32 = [](const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); };
+    if (srcSize >= 8 && (rd32(src) & 0xFFFFFFF0u) == 0x184D2A50u) {
+        const u64 sz = (u64)rd32(src + 4) + 8;
+        if (sz > srcSize) return ZERR(kErrSrcSizeWrong);
+        *bound = 0; return (size_t)sz;
+    }
+    if (srcSize < 5) return ZERR(kErrSrcSizeWrong);
+    if (rd32(src) != 0xFD2FB528u) return ZERR(kErrPrefixUnknown);
+    const u8 fhd = src[4];
+    static const size_t did[4] = { 0, 1, 2, 4 }, fcsB[4] = { 0, 2, 4, 8 };
+    const u32 single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    const size_t fhs = 5 + !single + did[fhd & 3] + fcsB[fcsId] + (single && !fcsId);
+    if (srcSize < fhs) return ZERR(kErrSrcSizeWrong);
+    if (fhd & 0x08) return ZERR(kErrFrameParameterUnsupported);
+    size_t pos = 5; u64 windowSize = 0, fcs = ~0ull;
+    if (!single) { const u8 wl = src[pos++]; const u32 wlog = (wl >> 3) + 10; if (wlog > 31) return ZERR(kErrWindowTooLarge); windowSize = 1ull << wlog; windowSize += (windowSize >> 3) * (wl & 7); }
+    pos += did[fhd & 3];
+    switch (fcsId) {
+    case 0: if (single) fcs = src[pos]; break;
+    case 1: fcs = (u64)((u32)src[pos] | ((u32)src[pos + 1] << 8)) + 256; break;
+    case 2: fcs = rd32(src + pos); break;
+    default: fcs = (u64)rd32(src + pos) | ((u64)rd32(src + pos + 4) << 32); break;
+    }
+    if (single) windowSize = fcs;
+    const u64 blockSizeMax = windowSize < (1u << 17) ? windowSize : (1u << 17);
+    const u8* ip = src + fhs; size_t remaining = srcSize - fhs; u64 nbBlocks = 0;
+    for (;;) {
+        if (remaining < 3) return ZERR(kErrSrcSizeWrong);
+        const u32 bh = (u32)ip[0] | ((u32)ip[1] << 8) | ((u32)ip[2] << 16);
+        const u32 last = bh & 1, type = (bh >> 1) & 3; u32 cSize = bh >> 3;
+        if (type == 3) return ZERR(kErrCorruption);
+        if (type == 1) cSize = 1;
+        if (3 + (size_t)cSize > remaining) return ZERR(kErrSrcSizeWrong);
+        ip += 3 + cSize; remaining -= 3 + cSize; nbBlocks++;
+        if (last) break;
+    }
+    if ((fhd >> 2) & 1) { if (remaining < 4) return ZERR(kErrSrcSizeWrong); ip += 4; }
+    *bound = fcs != ~0ull ? fcs : nbBlocks * blockSizeMax;
+    return (size_t)(ip - src);
+}
+
+static const u8* host_view(const void* src, size_t srcSize, std::vector<u8>& tmp)
+{
+    if (!is_device_ptr(src)) return (const u8*)src;
+    tmp.resize(srcSize);
+    if (hipMemcpy(tmp.data(), src, srcSize, hipMemcpyDeviceToHost) != hipSuccess) return nullptr;
+    return tmp.data();
+}
+
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize)
+{
+    std::vector<u8> tmp; const u8* ip = srcSize ? host_view(src, srcSize, tmp) : (const u8*)src;
+    if (srcSize && !ip) return (unsigned long long)0 - 2;
+    unsigned long long bound = 0;
+    while (srcSize > 0) {
+        unsigned long long b = 0; const size_t cs = host_frame_size_info(ip, srcSize, &b);
+        if (isErr(cs)) return (unsigned long long)0 - 2;
+        ip += cs; srcSize -= cs; bound += b;
+    }
+    return bound;
+}
+size_t ZSTD_findFrameCompressedSize(const void* src, size_t srcSize)
+{
+    std::vector<u8> tmp; const u8* ip = host_view(src, srcSize, tmp);
+    if (!ip) return ZERR(kErrSrcSizeWrong);
+    unsigned long long b; return host_frame_size_info(ip, srcSize, &b);
+}
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
+{
+    std::vector<u8> tmp; const size_t look = srcSize < 18 ? srcSize : 18;
+    const u8* ip = look ? host_view(src, look, tmp) : nullptr;
+    if (!ip || look < 5) return (unsigned long long)0 - 2;
+    auto rd32 = [](const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); };
+    if ((rd32(ip) & 0xFFFFFFF0u) == 0x184D2A50u) return 0;
+    if (rd32(ip) != 0xFD2FB528u) return (unsigned long long)0 - 2;
+    const u8 fhd = ip[4]; static const size_t did[4] = { 0, 1, 2, 4 }, fcsB[4] = { 0, 2, 4, 8 };
+    const u32 single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    const size_t fhs = 5 + !single + did[fhd & 3] + fcsB[fcsId] + (single && !fcsId);
+    if (look < fhs) return (unsigned long long)0 - 2;
+    size_t pos = 5 + !single + did[fhd & 3];
+    switch (fcsId) {
+    case 0: return single ? ip[pos] : (unsigned long long)0 - 1;
+    case 1: return (u64)((u32)ip[pos] | ((u32)ip[pos + 1] << 8)) + 256;
+    case 2: return rd32(ip + pos);
+    default: return (u64)rd32(ip + pos) | ((u64)rd32(ip + pos + 4) << 32);
+    }
+}
+
+static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+{
+    hipStream_t s = d->stream;
+    if (srcSize == 0) return 0;
+    // frames are at least 9 bytes; our own streams hold one per 64 KiB, foreign ones fewer
+    const u32 maxFrames = (u32)((srcSize / 9 + 1) < (1u << 22) ? (srcSize / 9 + 1) : (1u << 22));
+    if (!d->frames.ensure((size_t)maxFrames * sizeof(FrameDesc)) || !d->status.ensure(64)) return ZERR(kErrMemoryAllocation);
+    FrameDesc* frames = (FrameDesc*)d->frames.p; u32* status = (u32*)d->status.p;
+    d->timer.begin(s);
+    launch_frame_walk(d_src, srcSize, frames, maxFrames, status, s);       d->timer.mark("frame_walk", s);
+    u32 st[4] = { 0, 0, 0, 0 };
+    if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    if (st[1]) return ZERR(st[1]);
+    const u32 nFrames = st[0];
+    const u64 total = (u64)st[2] | ((u64)st[3] << 32);
+    if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
+    if (nFrames == 0) { d->timer.finish(); return 0; }
+    if (!d->frameErr.ensure((size_t)nFrames * sizeof(u32) + 64) || !d->scratch.ensure((size_t)nFrames * decode_scratch_per_frame() + 64)) return ZERR(kErrMemoryAllocation);
+    (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
+    launch_decode_frames(d_src, srcSize, d_dst, dstCapacity, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, s);
+    d->timer.mark("decode_frames", s);
+    u32 err = 0;
+    if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    d->timer.finish();
+    if (err) return ZERR(err);
+    return (size_t)total;
+}
+
+size_t ZSTDMI_decompressDevice(ZSTD_DCtx* d, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
+{
+    size_t e = dctx_bind(d); if (isErr(e)) return e;
+    if (srcSize && !d_src) return ZERR(kErrSrcSizeWrong);
+    return decompress_device(d, (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
+}
+
+size_t ZSTD_decompressDCtx(ZSTD_DCtx* d, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    size_t e = dctx_bind(d); if (isErr(e)) return e;
+    if (srcSize && !src) return ZERR(kErrSrcSizeWrong);
+    if (srcSize == 0) return 0;
+    const bool srcDev = is_device_ptr(src), dstDev = dst ? is_device_ptr(dst) : false;
+    const u8* d_src = (const u8*)src; u8* d_dst = (u8*)dst;
+    if (!srcDev) {
+        if (!d->stageSrc.ensure(srcSize + 64)) return ZERR(kErrMemoryAllocation);
+        if (hipMemcpyAsync(d->stageSrc.p, src, srcSize, hipMemcpyHostToDevice, d->stream) != hipSuccess) return ZERR(kErrGeneric);
+        d_src = (const u8*)d->stageSrc.p;
+    }
+    if (!dstDev) {
+        if (!d->stageDst.ensure(dstCapacity + 64)) return ZERR(kErrMemoryAllocation);
+        d_dst = (u8*)d->stageDst.p;
+    }
+    const size_t r = decompress_device(d, d_dst, dstCapacity, d_src, srcSize);
+    if (isErr(r)) return r;
+    if (!dstDev && r) {
+        if (hipMemcpyAsync(dst, d_dst, r, hipMemcpyDeviceToHost, d->stream) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(d->stream) != hipSuccess) return ZERR(kErrGeneric);
+    }
+    return r;
+}
+
+// ---------------- errors ----------------
+unsigned ZSTD_isError(size_t code) { return isErr(code); }
+const char* ZSTD_getErrorName(size_t code)
+{
+    if (!isErr(code)) return "No error detected";
+    switch ((u32)(0 - code)) {          // strings as U/ErrorPrivate.cs:35-180
+    case kErrGeneric: return "Error (generic)";
+    case kErrPrefixUnknown: return "Unknown frame descriptor";
+    case kErrVersionUnsupported: return "Version not supported";
+    case kErrFrameParameterUnsupported: return "Unsupported frame parameter";
+    case kErrWindowTooLarge: return "Frame requires too much memory for decoding";
+    case kErrCorruption: return "Corrupted block detected";
+    case kErrChecksumWrong: return "Restored data doesn't match checksum";
+    case kErrParameterUnsupported: return "Unsupported parameter";
+    case kErrParameterOutOfBound: return "Parameter is out of bound";
+    case kErrInitMissing: return "Context should be init first";
+    case kErrMemoryAllocation: return "Allocation error : not enough memory";
+    case kErrWorkSpaceTooSmall: return "workSpace buffer is not large enough";
+    case kErrStageWrong: return "Operation not authorized at current processing stage";
+    case kErrTableLogTooLarge: return "tableLog requires too much memory : unsupported";
+    case kErrMaxSymbolValueTooLarge: return "Unsupported max Symbol Value : too large";
+    case kErrMaxSymbolValueTooSmall: return "Specified maxSymbolValue is too small";
+    case kErrDictionaryCorrupted: return "Dictionary is corrupted";
+    case kErrDictionaryWrong: return "Dictionary mismatch";
+    case 34: return "Cannot create Dictionary from provided samples";
+    case kErrDstSizeTooSmall: return "Destination buffer is too small";
+    case kErrSrcSizeWrong: return "Src size is incorrect";
+    case kErrDstBufferNull: return "Operation on NULL destination buffer";
+    case 100: return "Frame index is too large";
+    case 102: return "An I/O error occurred when reading/seeking";
+    case 104: return "Destination buffer is wrong";
+    case 105: return "Source buffer is wrong";
+    default: return "Unspecified error code";
+    }
+}
+unsigned ZSTD_versionNumber(void) { return 10501; }
+const char* ZSTD_versionString(void) { return "1.5.1"; }
+
+size_t ZSTD_compressStream2(ZSTD_CCtx*, ZSTD_outBuffer*, ZSTD_inBuffer*, int) { return ZERR(kErrParameterUnsupported); }
+size_t ZSTD_decompressStream(ZSTD_DCtx*, ZSTD_outBuffer*, ZSTD_inBuffer*) { return ZERR(kErrParameterUnsupported); }
+
+// ---------------- extensions ----------------
+int ZSTDMI_deviceCount(void) { return device_count(); }
+size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kErrGeneric); if (c->deviceOk && device != c->device) return ZERR(kErrStageWrong); c->device = device; return 0; }
+size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
+size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
+size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* c, int en) { if (!c) return ZERR(kErrGeneric); c->timer.enabled = en != 0; return 0; }
+size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* d, int en) { if (!d) return ZERR(kErrGeneric); d->timer.enabled = en != 0; return 0; }
+int ZSTDMI_CCtx_getStageTimes(const ZSTD_CCtx* c, float* ms, const char** names, int cap)
+{
+    if (!c) return 0;
+    int n = c->nStages < cap ? c->nStages : cap;
+    for (int i = 0; i < n; i++) { if (ms) ms[i] = c->stageMs[i]; if (names) names[i] = c->stageNames[i]; }
+    return n;
+}
+int ZSTDMI_DCtx_getStageTimes(const ZSTD_DCtx* d, float* ms, const char** names, int cap)
+{
+    if (!d) return 0;
+    int n = d->timer.n < cap ? d->timer.n : cap;
+    for (int i = 0; i < n; i++) { if (ms) ms[i] = d->timer.ms[i]; if (names) names[i] = d->timer.names[i]; }
+    return n;
+}
+
+size_t ZSTDMI_debugGetChunk(ZSTD_CCtx* c, size_t chunkIdx, ZSTDMI_Seq* seqs, size_t seqCap, size_t* nbSeq, void* lits, size_t litCap, size_t* litSize)
+{
+    size_t e = cctx_bind(c); if (isErr(e)) return e;
+    if (chunkIdx >= c->lastChunks) return ZERR(kErrParameterOutOfBound);
+    ChunkMeta m;
+    if (hipMemcpy(&m, (ChunkMeta*)c->meta.p + chunkIdx, sizeof m, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    *nbSeq = m.nbSeq; *litSize = m.litSize;
+    const size_t ns = m.nbSeq < seqCap ? m.nbSeq : seqCap, nl = m.litSize < litCap ? m.litSize : litCap;
+    if (ns && hipMemcpy(seqs, (Seq*)c->seqs.p + chunkIdx * kMaxSeq, ns * sizeof(Seq), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    if (nl && hipMemcpy(lits, (u8*)c->lits.p + chunkIdx * kChunkSize, nl, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    return 0;
+}
+
+size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const ZSTDMI_Seq* seqs, size_t nbSeq,
+                                const void* lits, size_t litSize, size_t srcSize)
+{
+    size_t e = cctx_bind(c); if (isErr(e)) return e;
+    if (nbSeq > kMaxSeq || litSize > kChunkSize || srcSize > kChunkSize) return ZERR(kErrParameterOutOfBound);
+    if (!cctx_workspace(c, 1)) return ZERR(kErrMemoryAllocation);
+    hipStream_t s = c->stream;
+    ChunkMeta m = {}; m.srcSize = (u32)srcSize; m.nbSeq = (u32)nbSeq; m.litSize = (u32)litSize;
+    m.fhSize = 4 + 1 + (srcSize < 256 ? 1 : 2);
+    if (nbSeq) (void)hipMemcpyAsync(c->seqs.p, seqs, nbSeq * sizeof(Seq), hipMemcpyHostToDevice, s);
+    if (litSize) (void)hipMemcpyAsync(c->lits.p, lits, litSize, hipMemcpyHostToDevice, s);
+    (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
+    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, 1, s);
+    launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
+    launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, strategy_for_level(c->level), 0, s);
+    if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    if (m.blockType != 2) return 0;
+    if (m.bodySize > dstCapacity) return ZERR(kErrDstSizeTooSmall);
+    if (hipMemcpy(dst, (u8*)c->slots.p + m.fhSize + 3, m.bodySize, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    c->lastChunks = 1;
+    return m.bodySize;
+}
+
+} // extern "C"
