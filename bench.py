@@ -1,0 +1,199 @@
+#!/usr/bin/env python3
+"""bench.py — the hot path on BASELINE.json's metric: MB/s compress+decompress at zstd level 1.
+
+Workload (config.workload): BASELINE.json configs[1] — 1 GiB of i.i.d. Zipf(alpha=1.1) bytes per GPU, level 1,
+64 KiB independent chunks, input already resident in HBM.  One "step" = compress the whole buffer with the HIP
+pipeline and decompress the result with the HIP decoder (the metric names both directions); `value` is the
+uncompressed bytes of all ranks divided by the step time.  Compress-only and decompress-only rates (HIP events
+on the library's stream) are reported beside it.
+
+N > 1 (driver launches one rank per GPU via torch.distributed.run): every rank owns its own shard of chunks
+(weak scaling, no data-path collective on the input); the one real exchange step — the all-gather-v of the
+compressed shards over RCCL/xGMI that BASELINE.json's north_star names — runs on a side stream, overlapped with
+the decompress half of the step, and is inside the timed region.
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import threading
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+
+
+def make_zipf(n, seed, device):
+    import torch
+    gen = torch.Generator(device=device); gen.manual_seed(seed)
+    p = torch.arange(1, 257, dtype=torch.float64, device=device) ** -1.1
+    cdf = torch.cumsum(p / p.sum(), 0).float()
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    step = 1 << 28
+    for lo in range(0, n, step):
+        m = min(step, n - lo)
+        out[lo:lo + m] = torch.searchsorted(cdf, torch.rand(m, device=device, generator=gen)).clamp_(max=255).to(torch.uint8)
+    return out
+
+
+def stage_times(lib, ctx, getter):
+    ms = (ctypes.c_float * 16)(); names = (ctypes.c_char_p * 16)()
+    n = getter(ctx, ms, names, 16)
+    return {names[i].decode(): float(ms[i]) for i in range(n)}
+
+
+def cpu_baseline(sample: bytes, threads: int):
+    """The oracle (a plain-C port of the reference's level-1 path), same 64 KiB framing, on the host cores."""
+    import oracle_lib as o
+    n = len(sample)
+    t0 = time.perf_counter()
+    comp = o.compress(sample, 1, 0, 65536)
+    t1 = time.perf_counter()
+    back = o.decompress(comp, n)
+    t2 = time.perf_counter()
+    assert back == sample
+    one = dict(compress=n / (t1 - t0) / 1e6, decompress=n / (t2 - t1) / 1e6, roundtrip=n / (t2 - t0) / 1e6, ratio=len(comp) / n)
+    allc = None
+    if threads > 1:
+        per = (n // threads) // 65536 * 65536
+        parts = [sample[i * per:(i + 1) * per] for i in range(threads)]
+        def work(b):
+            c = o.compress(b, 1, 0, 65536); assert o.decompress(c, len(b)) == b
+        ths = [threading.Thread(target=work, args=(b,)) for b in parts]
+        t0 = time.perf_counter(); [t.start() for t in ths]; [t.join() for t in ths]; t1 = time.perf_counter()
+        allc = dict(roundtrip=per * threads / (t1 - t0) / 1e6, cores=threads)
+    return one, allc
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--size-mib", type=int, default=1024, help="uncompressed bytes per GPU (MiB)")
+    ap.add_argument("--input", default="zipf", choices=["zipf", "text"])
+    ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather-v of compressed shards")
+    ap.add_argument("--cpu-sample-mib", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import zstdsharp_amd as z
+    lib = z._ffi.load()
+    world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world == 1:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr); sys.exit(2)
+    assert lib.ZSTDMI_deviceCount() > local, "no MI355X visible: the product has no CPU fallback"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.size_mib << 20
+    if args.input == "zipf":
+        src = make_zipf(n, 1234 + rank, dev); workload = f"{args.size_mib} MiB Zipf(alpha=1.1) bytes per GPU, level 1 (ZSTD_fast), 64 KiB independent chunks"
+    else:
+        import datagen, numpy as np
+        base = datagen.text_like(64 << 20, 7 + rank)
+        src = torch.from_numpy(np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()).to(dev)
+        workload = f"{args.size_mib} MiB synthetic text (declared stand-in for Silesia dickens, absent offline), level 1, 64 KiB chunks"
+    cap = lib.ZSTD_compressBound(n)
+    dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    c, d = z.Compressor(1, device=local), z.Decompressor(device=local)
+    lib.ZSTDMI_CCtx_setProfiling(c.cctx, 1); lib.ZSTDMI_DCtx_setProfiling(d.dctx, 1)
+    comm = torch.cuda.Stream(device=dev) if world > 1 and not args.no_gather else None
+    gathered = None
+
+    def step():
+        nonlocal gathered
+        cs = lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), n)
+        assert cs < (1 << 63), lib.ZSTD_getErrorName(cs)
+        if comm is not None:
+            from zstdsharp_amd.dist import all_gather_sizes, all_gather_v
+            comm.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(comm):
+                sizes = all_gather_sizes(cs, dev)
+                gathered = all_gather_v(dst, cs, sizes, pad_to=(max(sizes) + 4095) // 4096 * 4096)
+        r = lib.ZSTDMI_decompressDevice(d.dctx, back.data_ptr(), n, dst.data_ptr(), cs)
+        assert r == n, lib.ZSTD_getErrorName(r)
+        if comm is not None:
+            torch.cuda.current_stream().wait_stream(comm)
+        return cs
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        cs = step()
+    sync()
+    acc_c, acc_d = {}, {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        cs = step()
+        for k, v in stage_times(lib, c.cctx, lib.ZSTDMI_CCtx_getStageTimes).items(): acc_c[k] = acc_c.get(k, 0.0) + v
+        for k, v in stage_times(lib, d.dctx, lib.ZSTDMI_DCtx_getStageTimes).items(): acc_d[k] = acc_d.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    ok = bool(torch.equal(src, back))                  # correctness gate: no throughput without a bit-exact round trip
+    if comm is not None and gathered is not None and rank == 0:
+        ok = ok and bool(torch.equal(gathered[:cs], dst[:cs]))
+    if dist is not None:
+        t = torch.tensor([1 if ok else 0], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok = bool(t.item())
+
+    if rank == 0:
+        K = args.steps
+        ms_step = elapsed / K * 1e3
+        ratio = cs / n
+        comp_ms = {k: v / K for k, v in acc_c.items()}; dec_ms = {k: v / K for k, v in acc_d.items()}
+        t_comp, t_dec = sum(comp_ms.values()), sum(dec_ms.values())
+        allk = {**{"compress/" + k: v for k, v in comp_ms.items()}, **{"decompress/" + k: v for k, v in dec_ms.items()}}
+        dom = max(allk, key=allk.get)
+        alg_bytes = (1.0 + ratio) * n                  # (1 + r) bytes per input byte, both directions
+        achieved = alg_bytes / (allk[dom] * 1e-3) / 1e9
+        line = {
+            "metric": "MB/s compress+decompress, level 1", "value": round(world * n / (elapsed / K) / 1e6, 1) if ok else None, "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": workload, "chunk": 65536, "framing": "one zstd frame per chunk",
+                       "gather": ("all-gather-v of compressed shards over RCCL, overlapped with decompress" if comm is not None else "none"),
+                       "parallelism": f"chunk-sharded x{world}"},
+            "round_trip_bit_exact": ok, "ratio": round(ratio, 5),
+            "compress_MBps_per_gpu": round(n / (t_comp * 1e-3) / 1e6, 1), "decompress_MBps_per_gpu": round(n / (t_dec * 1e-3) / 1e6, 1),
+            "stage_ms": {k: round(v, 4) for k, v in allk.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "hbm_read_frac": round(n / (allk[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            m = min(args.cpu_sample_mib << 20, n)
+            sample = src[:m].cpu().numpy().tobytes()
+            threads = max(1, min(16, len(os.sched_getaffinity(0))))
+            one, allc = cpu_baseline(sample, threads)
+            line["cpu_baseline"] = {"value": round(one["roundtrip"], 1), "unit": "MB/s", "cores": 1, "kind": "port",
+                                    "sample": f"first {m >> 20} MiB of the same buffer, oracle/ (C port of the reference's level-1 path), 64 KiB frames",
+                                    "compress_MBps": round(one["compress"], 1), "decompress_MBps": round(one["decompress"], 1), "ratio": round(one["ratio"], 5),
+                                    "all_cores": ({"value": round(allc["roundtrip"], 1), "cores": allc["cores"]} if allc else None)}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+    c.Dispose(); d.Dispose()
+    if not ok:
+        sys.exit(1)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,38 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    import oracle_lib
+    oracle_lib.lib()
+    return oracle_lib
+
+
+@pytest.fixture(scope="session")
+def golden():
+    import json
+    d = os.path.join(ROOT, "tests", "golden")
+    man = json.load(open(os.path.join(d, "manifest.json")))
+    for c in man["cases"]:
+        c["path"] = os.path.join(d, c["file"])
+    return man["cases"]
+
+
+@pytest.fixture(scope="session")
+def gpu_lib():
+    """The product library, bound through its C ABI.  Fails (not skips) if it cannot drive a GPU."""
+    import zstdsharp_amd
+    lib = zstdsharp_amd._ffi.load()
+    assert lib.ZSTDMI_deviceCount() > 0, "no gfx950 device visible: GPU tests need the HIP path, there is no fallback"
+    return lib

@@ -1,0 +1,53 @@
+"""CPU test of the N>1 path: world_size-2 gloo processes exercise the sharding and the all-gather-v used by bench.py."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def _worker(rank, world, port, total, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from zstdsharp_amd.dist import shard_range, all_gather_sizes, all_gather_v
+    lo, hi = shard_range(total, rank, world)
+    data = (torch.arange(total, dtype=torch.int64) * 7 % 251).to(torch.uint8)
+    # stand-in for "compress my shard": keep every third byte -> variable length per rank
+    mine = data[lo:hi][::3].contiguous()
+    buf = torch.zeros(hi - lo + 16, dtype=torch.uint8); buf[:mine.numel()] = mine
+    sizes = all_gather_sizes(mine.numel(), "cpu")
+    pad = max(sizes)
+    if buf.numel() < pad:
+        buf = torch.cat([buf, torch.zeros(pad - buf.numel(), dtype=torch.uint8)])
+    out = all_gather_v(buf, mine.numel(), sizes)
+    expect = torch.cat([data[slice(*shard_range(total, r, world))][::3] for r in range(world)])
+    q.put((rank, lo, hi, sizes, bool(torch.equal(out, expect))))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_shard_ranges_partition_the_input():
+    from zstdsharp_amd.dist import shard_range
+    for total in (0, 1, 65536, 65537, 10 * 65536 + 5, (1 << 30)):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(total, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == total
+            for (a, b), (c, d) in zip(edges, edges[1:]):
+                assert b == c and a <= b
+            assert all(lo % 65536 == 0 for lo, _ in edges)
+
+
+def test_all_gather_v_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total = 5 * 65536 + 1234
+    procs = [ctx.Process(target=_worker, args=(r, 2, 29641, total, q)) for r in range(2)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=120) for _ in procs)
+    [p.join(60) for p in procs]
+    assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == total
+    assert res[0][3] == res[1][3]
+    assert all(r[4] for r in res)

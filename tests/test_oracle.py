@@ -1,0 +1,106 @@
+"""CPU tests: the oracle against the committed golden vectors and the reference tests' known answers.
+
+The oracle is a restatement of the reference's algorithm (oracle/*.c).  It is pinned here by
+  * libzstd-produced frames (tests/golden, see make_golden.py for why libzstd stands in for the reference),
+  * the known answers of the reference's own tests (T/ZstdNetTests.cs), cited per test.
+"""
+import hashlib
+
+import pytest
+
+import datagen
+
+
+def _input(case):
+    return datagen.gen(case["kind"], case["n"], case["seed"]) * case["copies"]
+
+
+def test_decoder_matches_every_golden_frame(oracle, golden):
+    for c in golden:
+        blob = open(c["path"], "rb").read()
+        data = _input(c)
+        assert hashlib.sha256(data).hexdigest() == c["sha256"], c["file"]       # the generator still regenerates the input
+        assert oracle.lib().zso_decompressBound(blob, len(blob)) == len(data), c["file"]
+        assert oracle.decompress(blob, len(data)) == data, c["file"]
+
+
+# fixtures whose libzstd-1.5.7 bytes a faithful restatement of 1.5.1's level-1 path must reproduce exactly
+# (single-block frames: nothing 1.5.2+ changed is reachable; checked when the fixtures were generated)
+BYTE_IDENTICAL = ["bytei_0_l1", "bytei_1_l1", "bytei_2_l1", "bytei_3002_l1", "bytei_12002_l1", "bytei_99002_l1",
+                  "text_20000_l1", "zipf_65536_l1", "runs_50000_l1", "rand_5000_l1", "period_9000_l1", "zeros_200000_l1"]
+
+
+def test_encoder_reproduces_golden_level1_bytes(oracle, golden):
+    by_name = {c["file"][:-4]: c for c in golden}
+    for name in BYTE_IDENTICAL:
+        c = by_name[name]
+        assert oracle.compress(_input(c), c["level"], c["checksum"]) == open(c["path"], "rb").read(), name
+
+
+@pytest.mark.parametrize("kind", datagen.KINDS)
+def test_encoder_round_trip(oracle, kind):
+    for n in (0, 1, 6, 7, 8, 255, 256, 4096, 65535, 65536, 65537, 140000, 400000):
+        data = datagen.gen(kind, n, n)
+        for chunk in (0, 65536):
+            comp = oracle.compress(data, 1, 0, chunk)
+            assert isinstance(comp, bytes)
+            assert oracle.decompress(comp, n) == data, (kind, n, chunk)
+
+
+def test_generate_buffer_sizes_round_trip(oracle):
+    """T/ZstdNetTests.cs:478-496: (byte)i buffers of 2, 3002, ... 99002 bytes."""
+    for n in range(2, 100000, 3000):
+        data = datagen.gen("bytei", n)
+        assert oracle.decompress(oracle.compress(data, 1), n) == data
+
+
+def test_frame_header_known_answers(oracle):
+    """T/ZstdNetTests.cs:179-212: for a 256..65791-byte input, byte 4 is 0x60 (single segment, 2-byte FCS, no checksum,
+    no dictID) and the FCS field sits at byte 5 holding size-256."""
+    data = datagen.gen("text", 1000, 1)
+    comp = oracle.compress(data, 1)
+    assert comp[:4] == bytes([0x28, 0xB5, 0x2F, 0xFD])
+    assert comp[4] == 0x60
+    assert int.from_bytes(comp[5:7], "little") == 1000 - 256
+    # 64 KiB chunk of the GPU framing: 28 B5 2F FD 60 00 FF
+    comp = oracle.compress(datagen.gen("zipf", 65536, 2), 1)
+    assert comp[:7] == bytes([0x28, 0xB5, 0x2F, 0xFD, 0x60, 0x00, 0xFF])
+
+
+def test_checksum_adds_exactly_four_bytes(oracle):
+    """T/ZstdNetTests.cs:41-73."""
+    data = datagen.gen("text", 5000, 2)
+    a, b = oracle.compress(data, 1, 0), oracle.compress(data, 1, 1)
+    assert len(b) == len(a) + 4
+    assert oracle.decompress(b, len(data)) == data
+    corrupted = b[:-1] + bytes([b[-1] ^ 1])
+    assert oracle.decompress(corrupted, len(data)) == -22          # checksum_wrong
+
+
+def test_empty_and_one_byte(oracle):
+    """T/ZstdNetTests.cs:456-476."""
+    assert len(oracle.compress(b"", 1)) == 9
+    assert oracle.decompress(oracle.compress(b"", 1), 0) == b""
+    assert oracle.decompress(oracle.compress(bytes([42]), 1), 1) == bytes([42])
+
+
+def test_error_behaviour(oracle):
+    """T/ZstdNetTests.cs:166-258: garbage -> error; small destination -> dstSize_tooSmall (-70)."""
+    assert oracle.decompress(bytes(range(1, 20)), 100) == -10              # prefix_unknown
+    data = datagen.gen("text", 5000, 3)
+    comp = oracle.compress(data, 1)
+    assert oracle.decompress(comp, 20) == -70
+    assert isinstance(oracle.decompress(comp[:-3], len(data)), int)        # truncated
+    assert oracle.decompress(comp + b"\x00\x01", len(data)) == -72         # trailing garbage -> srcSize_wrong
+
+
+def test_xxh64_known_answers(oracle):
+    """XXH64 test vectors (seed 0) published with the xxHash specification."""
+    assert oracle.lib().zso_xxh64(b"", 0, 0) == 0xEF46DB3751D8E999
+    assert oracle.lib().zso_xxh64(b"a", 1, 0) == 0xD24EC4F1A98C6E5B
+    assert oracle.lib().zso_xxh64(b"abc", 3, 0) == 0x44BC2CF5AD770999
+
+
+def test_unrestated_strategies_are_refused_not_substituted(oracle):
+    data = datagen.gen("text", 300000, 1)
+    assert oracle.compress(data, 5) == -40          # greedy/row-hash is not restated yet: parameter_unsupported

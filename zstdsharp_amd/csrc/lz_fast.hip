@@ -9,7 +9,12 @@
 // (SURVEY.md §7 "valid zstd frames, not byte-identical frames"); repcode assignment follows the decoder's
 // history rule (U/ZstdDecompressBlock.cs:2387-2443) so every emitted offBase decodes to the intended offset.
 //
-// LDS (one workgroup per CU): chunk bytes 64 KiB (+pad) | hash table u32[8192] 32 KiB | tile arrays 3 KiB |
+// Candidates inside the same tile are found through a second table that keeps, per hash, the FIRST position of
+// the current tile (atomicMin with a tile stamp, so it needs no clearing and is order-independent): a lane whose
+// hash was already seen in its own tile matches against that nearer occurrence, which is what catches runs and
+// short-period data.  Both tables are updated with commutative atomics only, so the output is deterministic.
+//
+// LDS (one workgroup per CU): chunk bytes 64 KiB (+pad) | 2 hash tables u32[8192] 64 KiB | tile arrays 3 KiB |
 // coverage bitmask 8 KiB.  HBM traffic per chunk: read n, write literals (<= n) + 8 B per sequence.
 #include "zmi_device.h"
 
@@ -22,7 +27,8 @@ constexpr u32 kInPad    = 64;
 
 struct LzLds {
     u8  in[kChunkSize + kInPad];
-    u32 table[1u << kHashLog];           // position+1 of the latest earlier occurrence of the hash; 0 = empty
+    u32 table[1u << kHashLog];           // position+1 of the latest occurrence of the hash in EARLIER tiles; 0 = empty
+    u32 first[1u << kHashLog];           // first occurrence of the hash inside the CURRENT tile: ((63-tile) << 10) | index
     u16 tileOff[kTile];
     u8  tileLen[kTile];
     u32 cov[kChunkSize / 32];            // bit p set <=> byte p is covered by a selected match
@@ -136,7 +142,7 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
         for (u32 i = tid; i < n; i += kTile) L.in[i] = in[i];
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
-    for (u32 i = tid; i < (1u << kHashLog); i += kTile) L.table[i] = 0;
+    for (u32 i = tid; i < (1u << kHashLog); i += kTile) { L.table[i] = 0; L.first[i] = 0xFFFFFFFFu; }
     for (u32 i = tid; i < kChunkSize / 32; i += kTile) L.cov[i] = 0;
     __syncthreads();
 
@@ -149,9 +155,14 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
         const u32 p = t * kTile + tid;
         const bool valid = p + 8 <= n;
         u64 w = 0; u32 h = 0, cand = 0;
-        if (valid) { w = readLE64(L.in + p); h = hash6(w); cand = L.table[h]; }
+        const u32 stamp = (63u - t) << 10;
+        if (valid) { w = readLE64(L.in + p); h = hash6(w); cand = L.table[h]; atomicMin(&L.first[h], stamp | tid); }
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
-        if (valid) atomicMax(&L.table[h], p + 1);
+        if (valid) {
+            atomicMax(&L.table[h], p + 1);
+            const u32 f = L.first[h];          // same-tile first occurrence: nearer than anything in the cross-tile table
+            if ((f >> 10) == (63u - t) && (f & 1023u) < tid) cand = t * kTile + (f & 1023u) + 1;
+        }
         u32 len = 0, off = 0;
         if (cand) {
             const u32 cpos = cand - 1;

@@ -48,7 +48,7 @@ class ZstdException(Exception):
 
 
 def is_error(value: int) -> bool:
-    return value > SIZE_MAX - 120 + 1 - 1 and value > ((1 << 64) - 120)
+    return value > (1 << 64) - 120          # U/ErrorPrivate.cs:10-13
 
 
 def get_error_code(value: int) -> int:
