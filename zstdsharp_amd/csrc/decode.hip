@@ -1,15 +1,20 @@
 // decode.hip — zstd frame decoder on gfx950 (SURVEY.md §8 a-13 … a-17).
 //
-//   frame_walk_kernel    : ZSTD_findFrameSizeInfo over the whole input (U/ZstdDecompress.cs:877-951, 971-993):
-//                          headers only, produces the work list {srcOff, dstOff, srcSize, dstSize} per frame.
-//   decode_frames_kernel : one wave per frame (ZSTD_decompressFrame, U/ZstdDecompress.cs:1062-1214).  Frames are
-//                          independent (ZSTD_decompressBegin resets repcodes/tables per frame, :1933-1954), blocks
-//                          inside a frame are not (window history, repcodes, repeat tables), so the frame is the
-//                          unit of GPU parallelism.  Inside a block: Huffman weights + X1 table in LDS
-//                          (HUF_readStats U/EntropyCommon.cs:292-402, HUF_readDTableX1 U/HufDecompress.cs:80-251),
-//                          the four literal streams on four lanes (U/HufDecompress.cs:342-537), FSE sequence tables
-//                          in LDS (U/ZstdDecompressBlock.cs:1571-1943), the serial sequence state chain on lane 0
-//                          (:2360-2484) and 64-lane cooperative literal / match copies (:2187-2262).
+//   frame walk     : ZSTD_findFrameSizeInfo over the whole input (U/ZstdDecompress.cs:877-951, 971-993), headers only,
+//                    producing the work list {srcOff, dstOff, srcSize, dstSize} per frame.  Parallel form: the input is
+//                    cut into 128 KiB segments; one wave per segment scans for the first frame magic, validates it by
+//                    chaining frame -> frame until it leaves the segment, and a scan kernel checks that every
+//                    segment's exit is the next segment's entry (anything else — embedded frames inside raw blocks, a
+//                    corrupt header — falls back to the exact serial walk, which also produces the reference's error).
+//   literals kernel: one wave per frame (frames are independent: ZSTD_decompressBegin resets repcodes/tables per frame,
+//                    U/ZstdDecompress.cs:1933-1954; blocks inside a frame are not).  Per compressed block: Huffman
+//                    weights + X1 table in LDS (HUF_readStats U/EntropyCommon.cs:292-402, HUF_readDTableX1
+//                    U/HufDecompress.cs:80-251), the four literal streams on four lanes (U/HufDecompress.cs:342-537)
+//                    with a software-pipelined 64-bit bit window, literals written to an HBM scratch.
+//                    5 KiB of LDS per wave keeps 30 waves per CU resident, which is what hides the serial
+//                    table-lookup chain of each stream.
+//   sequences kernel: one wave per frame: FSE tables in LDS (U/ZstdDecompressBlock.cs:1571-1943), the serial sequence
+//                    state chain on lane 0 (:2360-2484), 64-lane cooperative literal / match copies (:2187-2262).
 // Results are bit-exact with the reference decoder by construction of the format; error codes follow
 // U/ZSTD_ErrorCode.cs (first failing frame wins).
 #include "zmi_device.h"
@@ -51,7 +56,7 @@ __device__ inline FrameHeader parse_frame_header(const u8* p, u64 avail)
     return h;
 }
 
-__global__ void frame_walk_kernel(const u8* __restrict__ src, u64 srcSize, FrameDesc* __restrict__ frames, u32 maxFrames, u32* __restrict__ status)
+__global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize, FrameDesc* __restrict__ frames, u32 maxFrames, u32* __restrict__ status)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u64 pos = 0, dstOff = 0; u32 n = 0, err = 0;
@@ -137,18 +142,24 @@ struct BackBits {
 // ------------------------------------------------------------------------------------------------
 struct SeqSym { u16 nextState; u8 nbAddBits; u8 nbBits; u32 baseValue; };
 
-struct DecLds {
-    u16 huf[4096];              // X1 table: byte | nbBits << 8
-    SeqSym ll[512], ml[512], of[256];
+// literals kernel: 5.5 KiB per wave
+struct LitLds {
+    u16 huf[2048];              // X1 table indexed by 11 bits: byte | nbBits << 8, or 0xF000 | pair for 12-bit codes
+    u16 pair[128][2];           // tableLog 12 only: the two 12-bit symbols that share an 11-bit prefix
     u8  weights[256];
     s16 norm[256];
     u16 symbolNext[256];
     u32 rankStart[16];
-    u32 llLog, mlLog, ofLog, hufLog;
-    u32 llValid, mlValid, ofValid, hufValid;
-    // FSE scratch for Huffman weights (tableLog <= 6)
-    u16 wNewState[64]; u8 wSymbol[64]; u8 wNbBits[64];
-    u32 bcast[8];
+    u32 hufLog, hufValid;
+    u16 wNewState[64]; u8 wSymbol[64]; u8 wNbBits[64];    // FSE scratch for Huffman weights (tableLog <= 6)
+};
+// sequences kernel: 10.6 KiB per wave
+struct SeqLds {
+    SeqSym ll[512], ml[512], of[256];
+    s16 norm[64];
+    u16 symbolNext[64];
+    u32 llLog, mlLog, ofLog;
+    u32 llValid, mlValid, ofValid;
 };
 
 __constant__ u8  dLL_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
@@ -243,7 +254,7 @@ __device__ inline void build_seq_dtable(SeqSym* t, u16* symbolNext, const s16* n
 }
 
 // ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), one lane.  Returns bytes consumed or 0xFFFFFFFF on error.
-__device__ inline u32 set_seq_table(DecLds& L, SeqSym* t, u32* logPtr, u32* validPtr, u32 type, u32 max, u32 maxLog,
+__device__ inline u32 set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32* validPtr, u32 type, u32 max, u32 maxLog,
                                     const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax)
 {
     switch (type) {
@@ -275,7 +286,7 @@ __device__ inline u32 set_seq_table(DecLds& L, SeqSym* t, u32* logPtr, u32* vali
 }
 
 // HUF_readStats (weights) on lane 0; returns bytes consumed or 0 on error.  nbSymbols/tableLog out.
-__device__ inline u32 huf_read_stats(DecLds& L, const u8* ip, u32 srcSize, u32* nbSymbolsPtr, u32* tableLogPtr)
+__device__ inline u32 huf_read_stats(LitLds& L, const u8* ip, u32 srcSize, u32* nbSymbolsPtr, u32* tableLogPtr)
 {
     if (!srcSize) return 0;
     u32 iSize = ip[0], oSize;
@@ -335,48 +346,235 @@ __device__ inline u32 huf_read_stats(DecLds& L, const u8* ip, u32 srcSize, u32* 
     return iSize + 1;
 }
 
-// one Huffman stream on one lane (HUF_decodeStreamX1, U/HufDecompress.cs:264-309); returns false on corruption
-__device__ inline bool huf_decode_stream(const u16* __restrict__ table, u32 tableLog, const u8* src, u32 srcSize, u8* __restrict__ out, u32 n)
+// ------------------------------------------------------------------------------------------------
+// Huffman literal streams
+// ------------------------------------------------------------------------------------------------
+// One stream on one lane (HUF_decodeStreamX1, U/HufDecompress.cs:264-309).  The reference keeps a 64-bit container and
+// reloads it every few symbols (BIT_reloadDStream, U/Bitstream.cs:377-419); here the 8 bytes BELOW the container are
+// fetched one reload ahead, so the HBM/L2 latency of the next reload is hidden behind the symbols of this one.
+// Returns false on corruption (stream not consumed exactly).
+template <bool TL12>
+__device__ __forceinline__ bool huf_decode_stream(const LitLds& L, u32 tableLog, const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
 {
-    BackBits bd;
-    if (!bd.init(src, (s32)srcSize)) return false;
-    for (u32 i = 0; i < n; i++) {
-        const u32 e = table[bd.peek(tableLog)];
-        out[i] = (u8)e;
-        bd.pos -= (s32)(e >> 8);
+    if (srcSize < 1) return false;
+    const u32 last = src[srcSize - 1];
+    if (!last) return false;
+    s32 remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);       // unread bits
+    const u32 idxBits = TL12 ? 11u : tableLog;
+    u32 i = 0; u64 acc = 0;
+    auto emit = [&](u32 sym) {
+        acc |= (u64)sym << (8 * (i & 7));
+        if ((i & 7) == 7) { *(u64u*)(out + i - 7) = acc; acc = 0; }
+        i++;
+    };
+    if (srcSize >= 16) {
+        u32 ptr = srcSize - 8;
+        u64 cont = readLE64(src + ptr), lower = readLE64(src + ptr - 8);
+        u32 consumed = 64u - (u32)(remaining - (s32)(8 * ptr));
+        bool lowerValid = true;
+        while (i < n) {
+            if (consumed > 52) {
+                if (!lowerValid) break;
+                const u32 k = consumed >> 3;
+                cont = k == 8 ? lower : ((cont << (8 * k)) | (lower >> (64 - 8 * k)));
+                ptr -= k; consumed -= 8 * k;
+                if (ptr >= 8) lower = readLE64(src + ptr - 8); else lowerValid = false;
+            }
+            const u64 top = cont << consumed;
+            u32 e = L.huf[(u32)(top >> (64 - idxBits))];
+            if (TL12 && e >= 0xF000u) e = (u32)L.pair[e & 0xFFFu][(u32)(top >> 52) & 1u] | (12u << 8);
+            consumed += e >> 8;
+            emit(e & 0xFFu);
+        }
+        remaining = (s32)(8 * ptr) + 64 - (s32)consumed;
     }
-    return bd.pos == 0;
+    if (i < n) {                         // short stream, or the last bytes of a long one: plain bit reader
+        BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
+        while (i < n) {
+            u32 e;
+            if (TL12) {
+                const u32 v = bd.peek(12);
+                e = L.huf[v >> 1];
+                if (e >= 0xF000u) e = (u32)L.pair[e & 0xFFFu][v & 1u] | (12u << 8);
+            } else e = L.huf[bd.peek(tableLog)];
+            bd.pos -= (s32)(e >> 8);
+            emit(e & 0xFFu);
+        }
+        remaining = bd.pos;
+    }
+    for (u32 k = 0; k < (n & 7); k++) out[(n & ~7u) + k] = (u8)(acc >> (8 * k));
+    return remaining == 0;
 }
 
-// 64-lane copies inside one wave; dst/src may be arbitrarily aligned
-__device__ __forceinline__ void wave_copy(u8* __restrict__ d, const u8* __restrict__ s, u32 n, u32 lane)
+// HUF_readDTableX1 (U/HufDecompress.cs:80-251): rank starts on lane 0, fill by all lanes.  tableLog 12 (legal, never
+// produced for zstd literals) is folded into the 11-bit table: codes of 12 bits share an 11-bit prefix pairwise.
+__device__ inline void huf_build_table(LitLds& L, u32 nbSymbols, u32 tableLog, u32 lane)
 {
-    for (u32 i = lane; i < n; i += 64) d[i] = s[i];
-}
-// match copy with the byte-wise overlap semantics of ZSTD_execSequence (U/ZstdDecompressBlock.cs:2247-2259):
-// every byte i of the match equals the byte `offset` behind it, so byte i = src0[i % offset] over the bytes that
-// existed before the match started.
-__device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 lane)
-{
-    const u8* s0 = d - offset;
-    if (offset >= n) { for (u32 i = lane; i < n; i += 64) d[i] = s0[i]; }
-    else { for (u32 i = lane; i < n; i += 64) d[i] = s0[i % offset]; }
+    if (lane == 0) {
+        u32 cnt[13]; for (int i = 0; i < 13; i++) cnt[i] = 0;
+        for (u32 n = 0; n < nbSymbols; n++) cnt[L.weights[n]]++;
+        u32 next = 0;
+        for (u32 w = 1; w <= tableLog; w++) { L.rankStart[w] = next; next += cnt[w] << (w - 1); }
+        for (u32 n = 0; n < nbSymbols; n++) {
+            const u32 w = L.weights[n];
+            if (w) { L.symbolNext[n] = (u16)L.rankStart[w]; L.rankStart[w] += (1u << w) >> 1; }
+        }
+        L.hufLog = tableLog; L.hufValid = 1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    const bool tl12 = tableLog == 12;
+    for (u32 n = lane; n < nbSymbols; n += 64) {
+        const u32 w = L.weights[n];
+        if (!w) continue;
+        const u32 len = (1u << w) >> 1, start = L.symbolNext[n];
+        const u16 e = (u16)(n | ((tableLog + 1 - w) << 8));
+        if (!tl12) { for (u32 u = 0; u < len; u++) L.huf[start + u] = e; }
+        else if (w == 1) { L.pair[start >> 1][start & 1] = (u16)n; L.huf[start >> 1] = (u16)(0xF000u | (start >> 1)); }
+        else { for (u32 u = 0; u < (len >> 1); u++) L.huf[(start >> 1) + u] = e; }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 }
 
 constexpr u32 kBlockMax = 1u << 17;
-constexpr u32 kScratchPerFrame = kBlockMax + 256;     // literal buffer of the current block
 
-// decodes one frame with one wave; returns 0 or a ZSTD_ErrorCode.  Every branch below is wave-uniform.
-__device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out, u8* __restrict__ litBuf, const u32 lane)
+struct LitHeader { u32 type, lhSize, litSize, litCSize, single, err; };
+// ZSTD_decodeLiteralsBlock header parse (U/ZstdDecompressBlock.cs:88-396)
+__device__ __forceinline__ LitHeader parse_lit_header(const u8* b, u32 bsz)
+{
+    LitHeader h; h.err = 0; h.single = 0; h.litCSize = 0;
+    h.type = b[0] & 3; const u32 lhl = (b[0] >> 2) & 3;
+    if (h.type >= 2) {
+        if (bsz < 5) { h.err = kErrCorruption; return h; }
+        const u32 lhc = readLE32(b);
+        switch (lhl) {
+        case 0: case 1: h.single = !lhl; h.lhSize = 3; h.litSize = (lhc >> 4) & 0x3FF; h.litCSize = (lhc >> 14) & 0x3FF; break;
+        case 2: h.lhSize = 4; h.litSize = (lhc >> 4) & 0x3FFF; h.litCSize = lhc >> 18; break;
+        default: h.lhSize = 5; h.litSize = (lhc >> 4) & 0x3FFFF; h.litCSize = (lhc >> 22) + ((u32)b[4] << 10); break;
+        }
+        if (h.litSize > kBlockMax || h.litCSize + h.lhSize > bsz) h.err = kErrCorruption;
+    } else {
+        switch (lhl) {
+        case 0: case 2: h.lhSize = 1; h.litSize = b[0] >> 3; break;
+        case 1: h.lhSize = 2; h.litSize = readLE16(b) >> 4; break;
+        default: h.lhSize = 3; h.litSize = readLE24(b) >> 4; break;
+        }
+        if (h.litSize > kBlockMax) h.err = kErrCorruption;
+        else if (h.type == 0 ? (h.lhSize + h.litSize > bsz) : (h.lhSize + 1 > bsz)) h.err = kErrCorruption;
+    }
+    return h;
+}
+
+// literals of every compressed block of one frame -> scratch (one wave; every branch is wave-uniform)
+__device__ u32 decode_frame_literals(LitLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 lane)
+{
+    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
+    u32 ip = h.headerSize, litOff = 0;
+    if (lane == 0) L.hufValid = 0;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    for (;;) {
+        if (fd.srcSize - ip < 3) return kErrSrcSizeWrong;
+        const u32 bh = readLE24(fsrc + ip);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        ip += 3;
+        if (type == 3) return kErrCorruption;
+        if (type == 1) { if (1 > fd.srcSize - ip) return kErrSrcSizeWrong; ip += 1; }
+        else {
+            if (bsz > fd.srcSize - ip) return kErrSrcSizeWrong;
+            if (type == 2) {
+                if (bsz >= kBlockMax) return kErrSrcSizeWrong;
+                if (bsz < 3) return kErrCorruption;
+                const u8* const b = fsrc + ip;
+                const LitHeader lh = parse_lit_header(b, bsz);
+                if (lh.err) return lh.err;
+                if (lh.type >= 2) {
+                    if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
+                    const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
+                    if (lh.type == 2) {
+                        u32 nbSymbols = 0, tableLog = 0, hs = 0;
+                        if (lane == 0) hs = huf_read_stats(L, hsrc, hlen, &nbSymbols, &tableLog);
+                        hs = uniform(hs); nbSymbols = uniform(nbSymbols); tableLog = uniform(tableLog);
+                        if (!hs || hs >= hlen) return kErrCorruption;
+                        huf_build_table(L, nbSymbols, tableLog, lane);
+                        hsrc += hs; hlen -= hs;
+                    } else if (!uniform(L.hufValid)) return kErrDictionaryCorrupted;
+                    const u32 tableLog = uniform(L.hufLog);
+                    u8* const dst = litOut + litOff;
+                    bool ok = true;
+                    if (lh.single) {
+                        if (lane == 0) ok = tableLog == 12 ? huf_decode_stream<true>(L, tableLog, hsrc, hlen, dst, lh.litSize)
+                                                           : huf_decode_stream<false>(L, tableLog, hsrc, hlen, dst, lh.litSize);
+                    } else {
+                        if (hlen < 10) return kErrCorruption;
+                        const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
+                        const u32 seg = (lh.litSize + 3) / 4;
+                        if (6 + l1 + l2 + l3 > hlen) return kErrCorruption;
+                        if (seg * 3 > lh.litSize) return kErrCorruption;
+                        const u32 l4 = hlen - 6 - l1 - l2 - l3;
+                        if (lane < 4) {
+                            const u32 so = lane == 0 ? 6 : lane == 1 ? 6 + l1 : lane == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
+                            const u32 sl = lane == 0 ? l1 : lane == 1 ? l2 : lane == 2 ? l3 : l4;
+                            const u32 on = lane < 3 ? seg : lh.litSize - 3 * seg;
+                            ok = tableLog == 12 ? huf_decode_stream<true>(L, tableLog, hsrc + so, sl, dst + lane * seg, on)
+                                                : huf_decode_stream<false>(L, tableLog, hsrc + so, sl, dst + lane * seg, on);
+                        }
+                    }
+                    if (ballot(!ok)) return kErrCorruption;
+                    litOff += lh.litSize;
+                }
+            }
+            ip += bsz;
+        }
+        if (last) break;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
+                                                             u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity)
+{
+    __shared__ LitLds L;
+    const u32 f = blockIdx.x, lane = threadIdx.x;
+    if (f >= nFrames) return;
+    const FrameDesc fd = frames[f];
+    if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
+    const u32 err = decode_frame_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, lane);
+    if (err && lane == 0) atomicCAS(frameErr, 0u, err);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sequences
+// ------------------------------------------------------------------------------------------------
+// 64-lane copies inside one wave; both sides may be arbitrarily aligned (gfx950 handles unaligned 8-byte accesses)
+__device__ __forceinline__ void wave_copy(u8* __restrict__ d, const u8* __restrict__ s, u32 n, u32 lane)
+{
+    if (n <= 64) { if (lane < n) d[lane] = s[lane]; return; }
+    const u32 chunks = n >> 4;
+    for (u32 i = lane; i < chunks; i += 64) {
+        const u64 a = readLE64(s + 16 * i), b = readLE64(s + 16 * i + 8);
+        *(u64u*)(d + 16 * i) = a; *(u64u*)(d + 16 * i + 8) = b;
+    }
+    const u32 done = chunks << 4;
+    if (lane < n - done) d[done + lane] = s[done + lane];
+}
+// match copy with the byte-wise overlap semantics of ZSTD_execSequence (U/ZstdDecompressBlock.cs:2247-2259): byte i of
+// the match equals the byte `offset` behind it, i.e. src0[i % offset] over the bytes that existed before the match.
+__device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 lane)
+{
+    const u8* s0 = d - offset;
+    if (offset >= n) { wave_copy(d, s0, n, lane); return; }
+    for (u32 i = lane; i < n; i += 64) d[i] = s0[i % offset];
+}
+
+__device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out,
+                                      const u8* __restrict__ litIn, const u32 lane)
 {
 #define FAIL(code) return (code)
-    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);     // validated by the walk; re-read for sizes/flags
-    u32 ip = h.headerSize;          // offset inside the frame
-    u32 op = 0;                     // bytes produced
+    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
+    u32 ip = h.headerSize, op = 0, litOff = 0;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;
-    if (lane == 0) { L.llValid = L.mlValid = L.ofValid = L.hufValid = 0; }
+    u32 fenced = 0;                       // output bytes [0, fenced) are known visible to every lane of this wave
+    if (lane == 0) { L.llValid = L.mlValid = L.ofValid = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-
     for (;;) {
         if (fd.srcSize - ip < 3) FAIL(kErrSrcSizeWrong);
         const u32 bh = readLE24(fsrc + ip);
@@ -395,100 +593,23 @@ __device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict_
             for (u32 i = lane; i < bsz; i += 64) out[op + i] = b;
             op += bsz; ip += 1;
         } else {
-            // ---------------- compressed block (ZSTD_decompressBlock_internal, U/ZstdDecompressBlock.cs:3090-3154) ----------------
             if (bsz > fd.srcSize - ip) FAIL(kErrSrcSizeWrong);
             if (bsz >= kBlockMax) FAIL(kErrSrcSizeWrong);
             if (bsz < 3) FAIL(kErrCorruption);
             const u8* const b = fsrc + ip; const u32 bend = bsz;
-            u32 bp = 0;
-            const u8* lit; u32 litSize;
-            {   // ---- literals section (ZSTD_decodeLiteralsBlock, :88-396) ----
-                const u32 ltype = b[0] & 3, lhl = (b[0] >> 2) & 3;
-                if (ltype >= 2) {
-                    if (bsz < 5) FAIL(kErrCorruption);
-                    const u32 lhc = readLE32(b);
-                    u32 lhSize, litCSize; bool single = false;
-                    switch (lhl) {
-                    case 0: case 1: single = !lhl; lhSize = 3; litSize = (lhc >> 4) & 0x3FF; litCSize = (lhc >> 14) & 0x3FF; break;
-                    case 2: lhSize = 4; litSize = (lhc >> 4) & 0x3FFF; litCSize = lhc >> 18; break;
-                    default: lhSize = 5; litSize = (lhc >> 4) & 0x3FFFF; litCSize = (lhc >> 22) + ((u32)b[4] << 10); break;
-                    }
-                    if (litSize > kBlockMax) FAIL(kErrCorruption);
-                    if (litCSize + lhSize > bsz) FAIL(kErrCorruption);
-                    const u8* hsrc = b + lhSize; u32 hlen = litCSize;
-                    if (ltype == 2) {
-                        u32 nbSymbols = 0, tableLog = 0, hs = 0;
-                        if (lane == 0) { hs = huf_read_stats(L, hsrc, hlen, &nbSymbols, &tableLog); }
-                        hs = uniform(hs); nbSymbols = uniform(nbSymbols); tableLog = uniform(tableLog);
-                        if (!hs || hs >= hlen) FAIL(kErrCorruption);
-                        // HUF_readDTableX1: rank starts on lane 0, table fill by all lanes
-                        if (lane == 0) {
-                            u32 cnt[13]; for (int i = 0; i < 13; i++) cnt[i] = 0;
-                            for (u32 n = 0; n < nbSymbols; n++) cnt[L.weights[n]]++;
-                            u32 next = 0;
-                            for (u32 w = 1; w <= tableLog; w++) { L.rankStart[w] = next; next += cnt[w] << (w - 1); }
-                            // per-symbol start offsets: reuse symbolNext as u16 start index (<= 4096)
-                            for (u32 n = 0; n < nbSymbols; n++) {
-                                const u32 w = L.weights[n];
-                                if (w) { L.symbolNext[n] = (u16)L.rankStart[w]; L.rankStart[w] += (1u << w) >> 1; }
-                            }
-                            L.hufLog = tableLog; L.hufValid = 1;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                        for (u32 n = lane; n < nbSymbols; n += 64) {
-                            const u32 w = L.weights[n];
-                            if (w) {
-                                const u32 len = (1u << w) >> 1, start = L.symbolNext[n];
-                                const u16 e = (u16)(n | ((tableLog + 1 - w) << 8));
-                                for (u32 u = 0; u < len; u++) L.huf[start + u] = e;
-                            }
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                        hsrc += hs; hlen -= hs;
-                    } else {
-                        if (!uniform(L.hufValid)) FAIL(kErrDictionaryCorrupted);
-                    }
-                    const u32 tableLog = uniform(L.hufLog);
-                    bool ok = true;
-                    if (single) {
-                        if (lane == 0) ok = huf_decode_stream(L.huf, tableLog, hsrc, hlen, litBuf, litSize);
-                    } else {
-                        if (hlen < 10) FAIL(kErrCorruption);
-                        const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
-                        const u32 seg = (litSize + 3) / 4;
-                        if (6 + l1 + l2 + l3 > hlen) FAIL(kErrCorruption);
-                        if (seg * 3 > litSize) FAIL(kErrCorruption);
-                        const u32 l4 = hlen - 6 - l1 - l2 - l3;
-                        if (lane < 4) {
-                            const u32 so = lane == 0 ? 6 : lane == 1 ? 6 + l1 : lane == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
-                            const u32 sl = lane == 0 ? l1 : lane == 1 ? l2 : lane == 2 ? l3 : l4;
-                            const u32 on = lane < 3 ? seg : litSize - 3 * seg;
-                            ok = huf_decode_stream(L.huf, tableLog, hsrc + so, sl, litBuf + lane * seg, on);
-                        }
-                    }
-                    if (ballot(!ok)) FAIL(kErrCorruption);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                    lit = litBuf; bp = lhSize + litCSize;
-                } else {
-                    u32 lhSize;
-                    switch (lhl) {
-                    case 0: case 2: lhSize = 1; litSize = b[0] >> 3; break;
-                    case 1: lhSize = 2; litSize = readLE16(b) >> 4; break;
-                    default: lhSize = 3; litSize = readLE24(b) >> 4; break;
-                    }
-                    if (litSize > kBlockMax) FAIL(kErrCorruption);
-                    if (ltype == 0) {
-                        if (lhSize + litSize > bsz) FAIL(kErrCorruption);
-                        lit = b + lhSize; bp = lhSize + litSize;
-                    } else {
-                        if (lhSize + 1 > bsz) FAIL(kErrCorruption);
-                        const u8 v = b[lhSize];
-                        for (u32 i = lane; i < litSize; i += 64) litBuf[i] = v;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                        lit = litBuf; bp = lhSize + 1;
-                    }
-                }
-            }
+            const LitHeader lh = parse_lit_header(b, bsz);
+            if (lh.err) FAIL(lh.err);
+            const u32 litSize = lh.litSize;
+            const u8* lit = nullptr; u32 rleByte = 0; bool litIsRle = false; u32 bp;
+            if (lh.type >= 2) {
+                if (litSize > fd.dstSize - litOff) FAIL(kErrCorruption);
+                lit = litIn + litOff; litOff += litSize; bp = lh.lhSize + lh.litCSize;
+            } else if (lh.type == 0) { lit = b + lh.lhSize; bp = lh.lhSize + litSize; }
+            else { litIsRle = true; rleByte = b[lh.lhSize]; bp = lh.lhSize + 1; }
+            auto copy_literals = [&](u32 dstOff, u32 litPos, u32 n) {
+                if (litIsRle) { for (u32 i = lane; i < n; i += 64) out[dstOff + i] = (u8)rleByte; }
+                else wave_copy(out + dstOff, lit + litPos, n, lane);
+            };
             // ---- sequences header (ZSTD_decodeSeqHeaders, :1845-1943) ----
             if (bp >= bend) FAIL(kErrSrcSizeWrong);
             u32 nbSeq = b[bp++];
@@ -518,13 +639,13 @@ __device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict_
             // ---- sequences (ZSTD_decompressSequences_body, :2668-2763) ----
             u32 litPos = 0;
             if (nbSeq) {
-                BackBits bd; bool okInit = true;
-                u32 sLL = 0, sOF = 0, sML = 0;
+                BackBits bd; bd.base = nullptr; bd.size = 0; bd.pos = 0; bd.win = 0; bd.wStart = 0;
+                u32 okInit = 1, sLL = 0, sOF = 0, sML = 0;
                 if (lane == 0) {
-                    okInit = bd.init(b + bp, (s32)(bend - bp));
+                    okInit = bd.init(b + bp, (s32)(bend - bp)) ? 1u : 0u;
                     if (okInit) { sLL = bd.read(L.llLog); sOF = bd.read(L.ofLog); sML = bd.read(L.mlLog); }
                 }
-                if (!uniform(okInit ? 1u : 0u)) FAIL(kErrCorruption);
+                if (!uniform(okInit)) FAIL(kErrCorruption);
                 for (u32 n = 0; n < nbSeq; n++) {
                     u32 litLength = 0, matchLength = 0, offset = 0;
                     if (lane == 0) {     // ZSTD_decodeSequence (:2360-2484)
@@ -557,13 +678,17 @@ __device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict_
                     // ZSTD_execSequence (:2187-2262)
                     if (litLength > litSize - litPos) FAIL(kErrCorruption);
                     if ((u64)litLength + matchLength > fd.dstSize - op) FAIL(kErrCorruption);
-                    wave_copy(out + op, lit + litPos, litLength, lane);
+                    copy_literals(op, litPos, litLength);
                     op += litLength; litPos += litLength;
-                    if (offset > op) FAIL(kErrCorruption);
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");       // earlier stores of this wave are visible to the match reads
+                    if (offset > op || offset == 0) FAIL(kErrCorruption);
+                    // the match reads [op-offset, op-offset+min(offset, matchLength)): stores of this wave that are not
+                    // yet known visible to its other lanes need one fence first
+                    {
+                        const u32 srcEnd = op - offset + (offset < matchLength ? offset : matchLength);
+                        if (srcEnd > fenced) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); fenced = op; }
+                    }
                     wave_match_copy(out + op, offset, matchLength, lane);
                     op += matchLength;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 }
                 u32 leftover = 0;
                 if (lane == 0) leftover = bd.pos > 0;
@@ -572,9 +697,8 @@ __device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict_
             {
                 const u32 lastLL = litSize - litPos;
                 if (lastLL > fd.dstSize - op) FAIL(kErrCorruption);
-                wave_copy(out + op, lit + litPos, lastLL, lane);
+                copy_literals(op, litPos, lastLL);
                 op += lastLL;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
             ip += bsz;
         }
@@ -583,6 +707,7 @@ __device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict_
     if (op != fd.dstSize) FAIL(kErrCorruption);           // regenerated size must equal the header's FCS (U/ZstdDecompress.cs:1177-1184)
     if (h.checksum) {
         // XXH64 of the regenerated frame: accumulators on lanes 0..3 (U/ZstdDecompress.cs:1186-1208)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
         auto rotl = [](u64 x, int r) { return (x << r) | (x >> (64 - r)); };
         auto rnd = [&](u64 acc, u64 in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
@@ -612,29 +737,187 @@ __device__ u32 decode_frame(DecLds& L, const FrameDesc fd, const u8* __restrict_
 #undef FAIL
 }
 
-__global__ __launch_bounds__(64) void decode_frames_kernel(const u8* __restrict__ src, u64 srcSize, u8* __restrict__ dst, u64 dstCapacity,
-                                                           const FrameDesc* __restrict__ frames, u32 nFrames, u32* __restrict__ frameErr,
-                                                           u8* __restrict__ scratch)
+__global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restrict__ src, u64 srcSize, u8* __restrict__ dst, u64 dstCapacity,
+                                                              const FrameDesc* __restrict__ frames, u32 nFrames, u32* __restrict__ frameErr,
+                                                              const u8* __restrict__ litScratch)
 {
-    __shared__ DecLds L;
+    __shared__ SeqLds L;
     const u32 f = blockIdx.x, lane = threadIdx.x;
     if (f >= nFrames) return;
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = decode_frame(L, fd, src + fd.srcOff, dst + fd.dstOff, scratch + (u64)f * kScratchPerFrame, lane);
+    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
 }
 
-size_t decode_scratch_per_frame() { return kScratchPerFrame; }
+// ------------------------------------------------------------------------------------------------
+// parallel frame walk
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kSegLog = 17;
+struct SegInfo { u64 entry, exit, dstBytes; u32 count, valid; };
 
-void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream)
+// one step of the chain: frame (or skippable frame) at pos -> next position.  status: 0 frame, 1 skippable, 2 invalid/unsupported
+__device__ inline u32 chain_step(const u8* __restrict__ src, u64 srcSize, u64 pos, u64* next, u32* content)
 {
-    hipLaunchKernelGGL(frame_walk_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status);
+    if (srcSize - pos < 5) return 2;
+    const u8* p = src + pos; const u64 avail = srcSize - pos;
+    const u32 magic = readLE32(p);
+    if ((magic & 0xFFFFFFF0u) == 0x184D2A50u) {
+        if (avail < 8) return 2;
+        const u64 sz = (u64)readLE32(p + 4) + 8;
+        if (sz > avail) return 2;
+        *next = pos + sz; *content = 0; return 1;
+    }
+    const FrameHeader h = parse_frame_header(p, avail);
+    if (h.err || h.dictID || h.contentSize > 0xFFFFFFFFull) return 2;
+    u64 q = pos + h.headerSize;
+    for (;;) {
+        if (srcSize - q < 3) return 2;
+        const u32 bh = readLE24(src + q);
+        const u32 last = bh & 1, type = (bh >> 1) & 3; u32 cSize = bh >> 3;
+        if (type == 3) return 2;
+        if (type == 1) cSize = 1;
+        if (3 + (u64)cSize > srcSize - q) return 2;
+        q += 3 + cSize;
+        if (last) break;
+    }
+    if (h.checksum) { if (srcSize - q < 4) return 2; q += 4; }
+    if (q - pos > 0xFFFFFFFFull) return 2;
+    *next = q; *content = (u32)h.contentSize; return 0;
 }
-void launch_decode_frames(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                          u8* scratch, hipStream_t stream)
+
+__global__ __launch_bounds__(64) void walk_segments_kernel(const u8* __restrict__ src, u64 srcSize, SegInfo* __restrict__ segs, u32 nSeg)
 {
-    hipLaunchKernelGGL(decode_frames_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, scratch);
+    const u32 s = blockIdx.x, lane = threadIdx.x;
+    if (s >= nSeg) return;
+    const u64 segStart = (u64)s << kSegLog;
+    const u64 segEnd = (segStart + (1ull << kSegLog)) < srcSize ? segStart + (1ull << kSegLog) : srcSize;
+    SegInfo r; r.entry = 0; r.exit = 0; r.dstBytes = 0; r.count = 0; r.valid = 0;
+    u64 scan = segStart;
+    while (scan < segEnd) {
+        // 64 lanes x 4 byte positions: a position p is a candidate if the dword at p is a frame or skippable-frame magic
+        const u64 base = scan + 4 * lane;
+        u64 w = 0;
+        if (base + 8 <= srcSize) w = readLE64(src + base);
+        else for (u32 k = 0; k < 8; k++) if (base + k < srcSize) w |= (u64)src[base + k] << (8 * k);
+        u32 hit = 4;
+#pragma unroll
+        for (int k = 3; k >= 0; k--) {
+            const u32 v = (u32)(w >> (8 * k));
+            if ((v == 0xFD2FB528u || (v & 0xFFFFFFF0u) == 0x184D2A50u) && base + k < segEnd) hit = k;
+        }
+        const u64 m = ballot(hit < 4);
+        if (!m) { scan += 256; continue; }
+        const u32 fl = ctz64(m);
+        const u64 cand = scan + 4 * fl + read_lane(hit, fl);
+        // validate by chaining until the chain leaves the segment (every lane walks the same chain: uniform)
+        u64 pos = cand, dstBytes = 0; u32 count = 0; bool ok = true;
+        while (pos < segEnd) {
+            u64 next = 0; u32 content = 0;
+            const u32 st = chain_step(src, srcSize, pos, &next, &content);
+            if (st == 2) { ok = false; break; }
+            if (st == 0) { count++; dstBytes += content; }
+            pos = next;
+        }
+        if (ok) { r.entry = cand; r.exit = pos; r.dstBytes = dstBytes; r.count = count; r.valid = 1; break; }
+        scan = cand + 1;           // false positive (or a corrupt stream: the link check then sends us to the serial walk)
+    }
+    if (lane == 0) segs[s] = r;
+}
+
+// single workgroup: link check + prefix sums.  status: [0]=nFrames [1]=err [2..3]=total [4]=1 when the parallel walk is usable
+__global__ __launch_bounds__(1024) void walk_link_kernel(const SegInfo* __restrict__ segs, u32 nSeg, u64 srcSize, u32 maxFrames,
+                                                         u32* __restrict__ frameBase, u64* __restrict__ dstBase, u32* __restrict__ status)
+{
+    __shared__ u64 sh64[16]; __shared__ u32 sh32[16]; __shared__ s32 shLast[16]; __shared__ u32 bad;
+    const u32 tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    if (tid == 0) bad = 0;
+    __syncthreads();
+    u64 carryDst = 0; u32 carryCnt = 0; s32 carryLast = -1;
+    for (u32 base = 0; base < nSeg; base += 1024) {
+        const u32 i = base + tid;
+        SegInfo g; g.valid = 0; g.count = 0; g.dstBytes = 0; g.entry = 0; g.exit = 0;
+        if (i < nSeg) g = segs[i];
+        // inclusive scans inside the wave: counts, bytes, index of the last valid segment
+        u32 c = g.valid ? g.count : 0; u64 b = g.valid ? g.dstBytes : 0; s32 lastv = g.valid ? (s32)i : -1;
+        u32 ci = c; u64 bi = b; s32 li = lastv;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const u32 tc = __shfl_up(ci, d); const u64 tb = __shfl_up(bi, d); const s32 tl = __shfl_up(li, d);
+            if ((int)lane >= d) { ci += tc; bi += tb; li = tl > li ? tl : li; }
+        }
+        if (lane == 63) { sh32[wave] = ci; sh64[wave] = bi; shLast[wave] = li; }
+        __syncthreads();
+        u32 cb = carryCnt; u64 bb = carryDst; s32 lb = carryLast; u32 call = 0; u64 ball = 0; s32 lall = -1;
+        for (u32 k = 0; k < 16; k++) {
+            if (k < wave) { cb += sh32[k]; bb += sh64[k]; lb = shLast[k] > lb ? shLast[k] : lb; }
+            call += sh32[k]; ball += sh64[k]; lall = shLast[k] > lall ? shLast[k] : lall;
+        }
+        // previous valid segment (exclusive): from the lanes before me in my wave, else from earlier waves / rounds
+        s32 prevInWave = __shfl_up(li, 1); if (lane == 0) prevInWave = -1;
+        const s32 prevValid = prevInWave > lb ? prevInWave : lb;
+        if (i < nSeg && g.valid) {
+            const u64 expect = prevValid >= 0 ? segs[prevValid].exit : 0;
+            if (g.entry != expect) atomicOr(&bad, 1u);
+            frameBase[i] = cb + ci - c; dstBase[i] = bb + bi - b;
+        }
+        carryCnt += call; carryDst += ball; carryLast = lall > carryLast ? lall : carryLast;
+        __syncthreads();
+    }
+    if (tid == 0) {
+        u32 usable = !bad;
+        if (carryLast < 0) usable = 0; else if (segs[carryLast].exit != srcSize) usable = 0;
+        if (carryCnt > maxFrames) usable = 0;
+        status[0] = carryCnt; status[1] = 0; status[2] = (u32)carryDst; status[3] = (u32)(carryDst >> 32); status[4] = usable;
+    }
+}
+
+__global__ __launch_bounds__(256) void walk_emit_kernel(const u8* __restrict__ src, u64 srcSize, const SegInfo* __restrict__ segs, u32 nSeg,
+                                                        const u32* __restrict__ frameBase, const u64* __restrict__ dstBase,
+                                                        const u32* __restrict__ status, FrameDesc* __restrict__ frames)
+{
+    const u32 s = blockIdx.x * 256 + threadIdx.x;
+    if (s >= nSeg || !status[4]) return;
+    const SegInfo g = segs[s];
+    if (!g.valid) return;
+    u64 pos = g.entry, dstOff = dstBase[s]; u32 idx = frameBase[s];
+    while (pos < g.exit) {
+        u64 next = 0; u32 content = 0;
+        const u32 st = chain_step(src, srcSize, pos, &next, &content);
+        if (st == 2) return;                                   // cannot happen: the chain was validated by walk_segments
+        if (st == 0) { FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.srcSize = (u32)(next - pos); f.dstSize = content; frames[idx++] = f; dstOff += content; }
+        pos = next;
+    }
+}
+
+size_t decode_walk_workspace_bytes(u64 srcSize)
+{
+    const u64 nSeg = (srcSize + (1ull << kSegLog) - 1) >> kSegLog;
+    return (size_t)(nSeg * (sizeof(SegInfo) + sizeof(u32) + sizeof(u64)) + 256);
+}
+
+void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, u8* walkWs, hipStream_t stream)
+{
+    const u32 nSeg = (u32)((srcSize + (1ull << kSegLog) - 1) >> kSegLog);
+    SegInfo* segs = reinterpret_cast<SegInfo*>(walkWs);
+    u64* dstBase = reinterpret_cast<u64*>(walkWs + (size_t)nSeg * sizeof(SegInfo));
+    u32* frameBase = reinterpret_cast<u32*>(walkWs + (size_t)nSeg * (sizeof(SegInfo) + sizeof(u64)));
+    hipLaunchKernelGGL(walk_segments_kernel, dim3(nSeg), dim3(64), 0, stream, src, srcSize, segs, nSeg);
+    hipLaunchKernelGGL(walk_link_kernel, dim3(1), dim3(1024), 0, stream, segs, nSeg, srcSize, maxFrames, frameBase, dstBase, status);
+    hipLaunchKernelGGL(walk_emit_kernel, dim3((nSeg + 255) / 256), dim3(256), 0, stream, src, srcSize, segs, nSeg, frameBase, dstBase, status, frames);
+}
+void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream)
+{
+    hipLaunchKernelGGL(frame_walk_serial_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status);
+}
+void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity, hipStream_t stream)
+{
+    hipLaunchKernelGGL(decode_literals_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity);
+}
+void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
+                             const u8* litScratch, hipStream_t stream)
+{
+    hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch);
 }
 
 } // namespace zmi

@@ -32,6 +32,7 @@ struct LzLds {
     u16 tileOff[kTile];
     u8  tileLen[kTile];
     u32 cov[kChunkSize / 32];            // bit p set <=> byte p is covered by a selected match
+    u64 tileMask[16];                    // per 64-position group of the current tile: lanes that hold a match
     u32 waveCnt[2][16];
     u32 nbSeq, anchorEnd;
 };
@@ -44,7 +45,11 @@ struct Walk { u32 cur, anchor, nbSeq, rep0, rep1, rep2; };
 __device__ __forceinline__ void walk_tile(LzLds& L, u32 n, u32 tileStart, Seq* __restrict__ seqOut, Walk& st)
 {
     const u32 lane = lane_id();
-    for (u32 g = 0; g < kTile / 64; ++g) {
+    // groups of this tile that hold at least one match: the walker only visits those
+    u64 groups = ballot(lane < kTile / 64 && L.tileMask[lane & 15] != 0);
+    while (groups) {
+        const u32 g = ctz64(groups);
+        groups &= groups - 1;
         const u32 gbase = tileStart + g * 64;
         if (st.cur >= gbase + 64) continue;
         const u32 myLen = L.tileLen[g * 64 + lane];
@@ -182,6 +187,7 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
             }
         }
         L.tileLen[tid] = (u8)len; L.tileOff[tid] = (u16)off;
+        { const u64 mm = ballot(len != 0); if (lane == 0) L.tileMask[wave] = mm; }
         __syncthreads();                       // tile arrays and inserts visible
         if (wave == 0) walk_tile(L, n, t * kTile, seqOut, st);
         // the other 15 waves run ahead into the next tile's probes; they meet wave 0 at that tile's first barrier
@@ -189,19 +195,32 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
     if (tid == 0) { L.nbSeq = st.nbSeq; }
     __syncthreads();
 
-    // ---- literals: every byte not covered by a selected match, in order ----
+    // ---- literals: every byte not covered by a selected match, in order; 16 positions per thread per round ----
     u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
     u32 litBase = 0;
-    for (u32 t = 0; t < nTiles; ++t) {
-        const u32 p = t * kTile + tid;
-        const bool isLit = p < n && !((L.cov[p >> 5] >> (p & 31)) & 1u);
-        const u64 b = ballot(isLit);
-        if (lane == 0) L.waveCnt[t & 1][wave] = popc64(b);
+    const u32 nRounds = (n + 16 * kTile - 1) / (16 * kTile);
+    for (u32 r = 0; r < nRounds; ++r) {
+        const u32 p = (r * kTile + tid) * 16;
+        u32 keep = 0;                                         // bit k set <=> byte p+k is a literal
+        if (p < n) {
+            const u32 covw = L.cov[p >> 5] >> (p & 31);       // p is a multiple of 16: the 16 bits sit in one word
+            keep = ~covw & 0xFFFFu;
+            if (n - p < 16) keep &= (1u << (n - p)) - 1;
+        }
+        const u32 cnt = __builtin_popcount(keep);
+        const u32 incl = wave_scan_incl(cnt);
+        if (lane == 63) L.waveCnt[r & 1][wave] = incl;
         __syncthreads();
         u32 before = 0, total = 0;
 #pragma unroll
-        for (u32 k = 0; k < 16; ++k) { const u32 v = L.waveCnt[t & 1][k]; total += v; if (k < wave) before += v; }
-        if (isLit) litOut[litBase + before + popc64(b & lanemask_lt())] = L.in[p];
+        for (u32 k = 0; k < 16; ++k) { const u32 v = L.waveCnt[r & 1][k]; total += v; if (k < wave) before += v; }
+        u8* o = litOut + litBase + before + incl - cnt;
+        if (keep == 0xFFFFu) {
+            const uint4 v = *reinterpret_cast<const uint4*>(L.in + p);
+            *(u32u*)(o) = v.x; *(u32u*)(o + 4) = v.y; *(u32u*)(o + 8) = v.z; *(u32u*)(o + 12) = v.w;
+        } else {
+            while (keep) { const u32 k = __builtin_ctz(keep); keep &= keep - 1; *o++ = L.in[p + k]; }
+        }
         litBase += total;
     }
     if (tid == 0) {

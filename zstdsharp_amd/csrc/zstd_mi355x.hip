@@ -2,7 +2,7 @@
 // launch sequences of the compress / decompress pipelines.  The C ABI is declared in include/zstd_mi355x.h.
 //
 // There is no CPU codec in this library: without a usable gfx950 device every compress/decompress call returns
-// ZSTD_error_GENERIC... no — it returns memory_allocation from context creation or init_missing from the call, loudly.
+// ZSTD_error_init_missing, loudly.
 #include <hip/hip_runtime.h>
 #include <stdlib.h>
 #include <string.h>
@@ -23,12 +23,13 @@ void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta*
                    u32 nChunks, hipStream_t stream);
 void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, hipStream_t stream);
 // decoder
-struct DecodeWork;
-size_t decode_workspace_bytes(u32 maxFrames);
-void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total lo/hi*/, hipStream_t stream);
-void launch_decode_frames(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                          u8* scratch, hipStream_t stream);
-size_t decode_scratch_per_frame();
+size_t decode_walk_workspace_bytes(u64 srcSize);
+void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total [4]=usable*/,
+                       u8* walkWs, hipStream_t stream);
+void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream);
+void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity, hipStream_t stream);
+void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
+                             const u8* litScratch, hipStream_t stream);
 }
 
 using namespace zmi;
@@ -62,7 +63,6 @@ struct StageTimer {
     void begin(hipStream_t s) { n = 0; if (!enabled) return; if (!created) { for (auto& e : ev) (void)hipEventCreate(&e); created = true; } (void)hipEventRecord(ev[0], s); }
     void mark(const char* name, hipStream_t s) { if (!enabled || n >= kMaxStages) return; names[n] = name; (void)hipEventRecord(ev[n + 1], s); n++; }
     void finish() { if (!enabled) return; for (int i = 0; i < n; i++) { float t = 0; (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]); ms[i] = t; } }
-    void accumulate(StageTimer& into) { (void)into; }
     void destroy() { if (created) for (auto& e : ev) (void)hipEventDestroy(e); created = false; }
 };
 
@@ -100,7 +100,7 @@ struct ZSTD_DCtx_s {
     int windowLogMax = 27;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf frames, status, frameErr, scratch, stageSrc, stageDst;
+    DevBuf frames, status, frameErr, scratch, walkWs, stageSrc, stageDst;
     StageTimer timer;
 };
 
@@ -162,7 +162,6 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = strategy_for_level(c->level);
     size_t produced = 0;
-    c->timer.enabled = c->timer.enabled;   // keep
     bool first = true;
     for (u64 c0 = 0; c0 < totalChunks; c0 += passChunks) {
         const u32 nChunks = (u32)((totalChunks - c0) < passChunks ? (totalChunks - c0) : passChunks);
@@ -183,7 +182,6 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
         if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
         if (first) { c->timer.finish(); c->nStages = c->timer.n; for (int i = 0; i < c->timer.n; i++) { c->stageMs[i] = c->timer.ms[i]; c->stageNames[i] = c->timer.names[i]; } }
-        else if (c->timer.enabled) { /* later passes are not re-timed */ }
         first = false;
         if (passTotal > room) return ZERR(kErrDstSizeTooSmall);
         produced += (size_t)passTotal;
@@ -322,7 +320,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->stageSrc.release(); d->stageDst.release();
+        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->stageSrc.release(); d->stageDst.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -443,24 +441,30 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
 {
     hipStream_t s = d->stream;
     if (srcSize == 0) return 0;
-    // frames are at least 9 bytes; our own streams hold one per 64 KiB, foreign ones fewer
+    // a frame is at least 9 bytes; our own streams hold one per 64 KiB, foreign ones usually far fewer
     const u32 maxFrames = (u32)((srcSize / 9 + 1) < (1u << 22) ? (srcSize / 9 + 1) : (1u << 22));
-    if (!d->frames.ensure((size_t)maxFrames * sizeof(FrameDesc)) || !d->status.ensure(64)) return ZERR(kErrMemoryAllocation);
+    if (!d->frames.ensure((size_t)maxFrames * sizeof(FrameDesc)) || !d->status.ensure(64) || !d->walkWs.ensure(decode_walk_workspace_bytes(srcSize)))
+        return ZERR(kErrMemoryAllocation);
     FrameDesc* frames = (FrameDesc*)d->frames.p; u32* status = (u32*)d->status.p;
     d->timer.begin(s);
-    launch_frame_walk(d_src, srcSize, frames, maxFrames, status, s);       d->timer.mark("frame_walk", s);
-    u32 st[4] = { 0, 0, 0, 0 };
+    launch_frame_walk(d_src, srcSize, frames, maxFrames, status, (u8*)d->walkWs.p, s);       d->timer.mark("frame_walk", s);
+    u32 st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    if (!st[4]) {       // the segment links did not close: take the exact serial walk (it also yields the reference's error code)
+        launch_frame_walk_serial(d_src, srcSize, frames, maxFrames, status, s);
+        if (hipMemcpyAsync(st, status, 4 * sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    }
     if (st[1]) return ZERR(st[1]);
     const u32 nFrames = st[0];
     const u64 total = (u64)st[2] | ((u64)st[3] << 32);
     if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
     if (nFrames == 0) { d->timer.finish(); return 0; }
-    if (!d->frameErr.ensure((size_t)nFrames * sizeof(u32) + 64) || !d->scratch.ensure((size_t)nFrames * decode_scratch_per_frame() + 64)) return ZERR(kErrMemoryAllocation);
+    if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + 256)) return ZERR(kErrMemoryAllocation);
     (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
-    launch_decode_frames(d_src, srcSize, d_dst, dstCapacity, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, s);
-    d->timer.mark("decode_frames", s);
+    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, s);     d->timer.mark("decode_literals", s);
+    launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, s);   d->timer.mark("decode_sequences", s);
     u32 err = 0;
     if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
