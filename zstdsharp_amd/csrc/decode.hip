@@ -286,7 +286,8 @@ __device__ inline u32 set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32* vali
 }
 
 // HUF_readStats (weights) on lane 0; returns bytes consumed or 0 on error.  nbSymbols/tableLog out.
-__device__ inline u32 huf_read_stats(LitLds& L, const u8* ip, u32 srcSize, u32* nbSymbolsPtr, u32* tableLogPtr)
+template <class Scratch>
+__device__ inline u32 huf_read_stats(Scratch& L, const u8* ip, u32 srcSize, u32* nbSymbolsPtr, u32* tableLogPtr)
 {
     if (!srcSize) return 0;
     u32 iSize = ip[0], oSize;
@@ -529,16 +530,186 @@ __device__ u32 decode_frame_literals(LitLds& L, const FrameDesc fd, const u8* __
     return 0;
 }
 
-__global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
-                                                             u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity)
+// slow path: one frame per wave, handles everything (incl. 12-bit Huffman tables); only runs for frames the quad kernel flagged
+__global__ __launch_bounds__(64) void decode_literals_slow_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
+                                                                  u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
+                                                                  const u8* __restrict__ slowFlags)
 {
     __shared__ LitLds L;
     const u32 f = blockIdx.x, lane = threadIdx.x;
-    if (f >= nFrames) return;
+    if (f >= nFrames || !slowFlags[f]) return;
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
     const u32 err = decode_frame_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, lane);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// literals, fast path: kQuads frames per wave, 4 lanes (one per Huffman stream) per frame
+// ------------------------------------------------------------------------------------------------
+// The four streams of a block are four serial table-lookup chains, so a frame can keep only four lanes busy, and a
+// frame needs its 4 KiB X1 table in LDS.  What bounds the kernel is therefore LDS capacity (32 frames = 128 busy
+// lanes per CU) and the length of one lookup step; packing 8 frames into a wave lets one wave instruction advance
+// 32 streams instead of 4, which is what the one-frame-per-wave form wasted its issue slots on.
+constexpr u32 kQuads = 8;
+struct QuadLds {
+    u16 huf[2048];              // X1 table (tableLog <= 11).  Before it is filled, its storage holds the FSE scratch below.
+    u8  weights[256];
+    u16 start[256];             // first table index of each symbol
+    u32 meta[4];                // hs, nbSymbols, tableLog, valid
+};
+struct QuadScratch {            // view used by huf_read_stats: FSE scratch aliased onto the (not yet built) table
+    u8* weights; s16* norm; u16* symbolNext; u16* wNewState; u8* wSymbol; u8* wNbBits;
+};
+
+// 4 symbols per step into one dword; container reload every step, next reload prefetched (see huf_decode_stream)
+__device__ __forceinline__ bool huf_decode_stream4(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ src, u32 srcSize,
+                                                   u8* __restrict__ out, u32 n)
+{
+    if (srcSize < 1) return false;
+    const u32 last = src[srcSize - 1];
+    if (!last) return false;
+    s32 remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+    u32 i = 0;
+    if (srcSize >= 16) {
+        u32 ptr = srcSize - 8;
+        u64 cont = readLE64(src + ptr), lower = readLE64(src + ptr - 8);
+        u32 consumed = 64u - (u32)(remaining - (s32)(8 * ptr));
+        bool lowerValid = true;
+        const u32 sh = 32 - tableLog;
+        while (i + 4 <= n) {
+            if (consumed > 20) {                   // 4 codes need up to 44 bits
+                if (!lowerValid) break;
+                const u32 k = consumed >> 3;
+                cont = k == 8 ? lower : ((cont << (8 * k)) | (lower >> (64 - 8 * k)));
+                ptr -= k; consumed -= 8 * k;
+                if (ptr >= 8) lower = readLE64(src + ptr - 8); else lowerValid = false;
+            }
+            u32 e, word;
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word = e & 0xFFu;
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 8;
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 16;
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 24;
+            *(u32u*)(out + i) = word;
+            i += 4;
+        }
+        remaining = (s32)(8 * ptr) + 64 - (s32)consumed;
+    }
+    if (i < n) {
+        BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
+        while (i < n) { const u32 e = table[bd.peek(tableLog)]; bd.pos -= (s32)(e >> 8); out[i++] = (u8)e; }
+        remaining = bd.pos;
+    }
+    return remaining == 0;
+}
+
+// One frame on the 4 lanes of a quad.  Header parsing is done redundantly by the 4 lanes (same loads, same values, so
+// the quad's control flow is uniform without any cross-lane traffic); only the weight decoding runs on the quad leader.
+// Returns an error code, or 0xFFFF to ask for the slow path (12-bit table).
+__device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 ql)
+{
+    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
+    u32 ip = h.headerSize, litOff = 0;
+    bool haveTable = false; u32 tableLog = 0;
+    for (;;) {
+        if (fd.srcSize - ip < 3) return kErrSrcSizeWrong;
+        const u32 bh = readLE24(fsrc + ip);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        ip += 3;
+        if (type == 3) return kErrCorruption;
+        if (type == 1) { if (1 > fd.srcSize - ip) return kErrSrcSizeWrong; ip += 1; }
+        else {
+            if (bsz > fd.srcSize - ip) return kErrSrcSizeWrong;
+            if (type == 2) {
+                if (bsz >= kBlockMax) return kErrSrcSizeWrong;
+                if (bsz < 3) return kErrCorruption;
+                const u8* const b = fsrc + ip;
+                const LitHeader lh = parse_lit_header(b, bsz);
+                if (lh.err) return lh.err;
+                if (lh.type >= 2) {
+                    if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
+                    const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
+                    if (lh.type == 2) {
+                        if (ql == 0) {
+                            QuadScratch sc;
+                            sc.weights = Q.weights; sc.norm = reinterpret_cast<s16*>(Q.huf); sc.symbolNext = Q.huf + 256;
+                            sc.wNewState = Q.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(Q.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(Q.huf + 608);
+                            u32 nbSymbols = 0, tl = 0;
+                            const u32 hs = huf_read_stats(sc, hsrc, hlen, &nbSymbols, &tl);
+                            if (hs && tl <= 11) {          // rank starts -> per-symbol first index (HUF_readDTableX1)
+                                u32 cnt[13]; for (int i = 0; i < 13; i++) cnt[i] = 0;
+                                for (u32 n = 0; n < nbSymbols; n++) cnt[Q.weights[n]]++;
+                                u32 rs[13]; u32 next = 0;
+                                for (u32 w = 1; w <= tl; w++) { rs[w] = next; next += cnt[w] << (w - 1); }
+                                for (u32 n = 0; n < nbSymbols; n++) { const u32 w = Q.weights[n]; if (w) { Q.start[n] = (u16)rs[w]; rs[w] += (1u << w) >> 1; } }
+                            }
+                            Q.meta[0] = hs; Q.meta[1] = nbSymbols; Q.meta[2] = tl;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        const u32 hs = Q.meta[0], nbSymbols = Q.meta[1]; tableLog = Q.meta[2];
+                        if (!hs || hs >= hlen) return kErrCorruption;
+                        if (tableLog > 11) return 0xFFFFu;
+                        for (u32 n = ql; n < nbSymbols; n += 4) {          // table fill, 4 lanes
+                            const u32 w = Q.weights[n];
+                            if (!w) continue;
+                            const u32 len = (1u << w) >> 1, st = Q.start[n];
+                            const u32 e = n | ((tableLog + 1 - w) << 8);
+                            if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
+                            else for (u32 u = 0; u < len; u++) Q.huf[st + u] = (u16)e;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        haveTable = true;
+                        hsrc += hs; hlen -= hs;
+                    } else if (!haveTable) return kErrDictionaryCorrupted;
+                    u8* const dst = litOut + litOff;
+                    bool ok = true;
+                    if (lh.single) {
+                        if (ql == 0) ok = huf_decode_stream4(Q.huf, tableLog, hsrc, hlen, dst, lh.litSize);
+                    } else {
+                        if (hlen < 10) return kErrCorruption;
+                        const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
+                        const u32 seg = (lh.litSize + 3) / 4;
+                        if (6 + l1 + l2 + l3 > hlen) return kErrCorruption;
+                        if (seg * 3 > lh.litSize) return kErrCorruption;
+                        const u32 l4 = hlen - 6 - l1 - l2 - l3;
+                        const u32 so = ql == 0 ? 6 : ql == 1 ? 6 + l1 : ql == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
+                        const u32 sl = ql == 0 ? l1 : ql == 1 ? l2 : ql == 2 ? l3 : l4;
+                        const u32 on = ql < 3 ? seg : lh.litSize - 3 * seg;
+                        ok = huf_decode_stream4(Q.huf, tableLog, hsrc + so, sl, dst + ql * seg, on);
+                    }
+                    // any stream of the quad failing fails the frame: combine through LDS (the 4 lanes are converged here)
+                    if (ql == 0) Q.meta[3] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    if (!ok) Q.meta[3] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    if (Q.meta[3]) return kErrCorruption;
+                    litOff += lh.litSize;
+                }
+            }
+            ip += bsz;
+        }
+        if (last) break;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
+                                                             u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
+                                                             u8* __restrict__ slowFlags)
+{
+    __shared__ QuadLds Qs[kQuads];
+    const u32 lane = threadIdx.x, q = lane >> 2, ql = lane & 3;
+    const u32 f = blockIdx.x * kQuads + q;
+    if (q >= kQuads || f >= nFrames) return;
+    const FrameDesc fd = frames[f];
+    if (ql == 0) slowFlags[f] = 0;
+    if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (ql == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
+    const u32 err = quad_decode_literals(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql);
+    if (ql == 0) {
+        if (err == 0xFFFFu) slowFlags[f] = 1;
+        else if (err) atomicCAS(frameErr, 0u, err);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -910,9 +1081,11 @@ void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32
 {
     hipLaunchKernelGGL(frame_walk_serial_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status);
 }
-void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity, hipStream_t stream)
+void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
+                            u8* slowFlags, hipStream_t stream)
 {
-    hipLaunchKernelGGL(decode_literals_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity);
+    hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
+    hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
 }
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
                              const u8* litScratch, hipStream_t stream)

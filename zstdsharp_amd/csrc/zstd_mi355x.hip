@@ -27,7 +27,8 @@ size_t decode_walk_workspace_bytes(u64 srcSize);
 void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total [4]=usable*/,
                        u8* walkWs, hipStream_t stream);
 void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream);
-void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity, hipStream_t stream);
+void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
+                            u8* slowFlags, hipStream_t stream);
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
                              const u8* litScratch, hipStream_t stream);
 }
@@ -100,7 +101,7 @@ struct ZSTD_DCtx_s {
     int windowLogMax = 27;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf frames, status, frameErr, scratch, walkWs, stageSrc, stageDst;
+    DevBuf frames, status, frameErr, scratch, walkWs, slowFlags, stageSrc, stageDst;
     StageTimer timer;
 };
 
@@ -320,7 +321,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->stageSrc.release(); d->stageDst.release();
+        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -461,9 +462,9 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     const u64 total = (u64)st[2] | ((u64)st[3] << 32);
     if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
     if (nFrames == 0) { d->timer.finish(); return 0; }
-    if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + 256)) return ZERR(kErrMemoryAllocation);
+    if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
     (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
-    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, s);     d->timer.mark("decode_literals", s);
+    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, s);     d->timer.mark("decode_literals", s);
     launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, s);   d->timer.mark("decode_sequences", s);
     u32 err = 0;
     if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
