@@ -563,29 +563,25 @@ struct QuadScratch {            // view used by huf_read_stats: FSE scratch alia
     u8* weights; s16* norm; u16* symbolNext; u16* wNewState; u8* wSymbol; u8* wNbBits;
 };
 
-// 4 symbols per step into one dword; container reload every step, next reload prefetched (see huf_decode_stream)
+// 4 symbols per step into one dword.  The loop body is branch-free: the container is re-based on EVERY step (by
+// consumed/8 bytes, possibly 0) from `lower`, the 8 stream bytes below it, whose load was issued one step earlier;
+// bytes below the stream start read as zero.  Keeping the refill unconditional is what lets the compiler place a
+// counted s_waitcnt in front of the use instead of draining every store (vmcnt counts loads and stores together).
 __device__ __forceinline__ bool huf_decode_stream4(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ src, u32 srcSize,
                                                    u8* __restrict__ out, u32 n)
 {
     if (srcSize < 1) return false;
-    const u32 last = src[srcSize - 1];
-    if (!last) return false;
-    s32 remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-    u32 i = 0;
+    s32 remaining; u32 i = 0;
     if (srcSize >= 16) {
-        u32 ptr = srcSize - 8;
-        u64 cont = readLE64(src + ptr), lower = readLE64(src + ptr - 8);
-        u32 consumed = 64u - (u32)(remaining - (s32)(8 * ptr));
-        bool lowerValid = true;
+        s32 ptr = (s32)srcSize - 8;                                    // byte index of the container; may go negative at the very end
+        u64 cont = readLE64(src + ptr);
+        u64 raw = readLE64(src + ptr - 8); s32 lp = ptr - 8;           // the 8 bytes below the container, fetched one step ahead
+        const u32 last = (u32)(cont >> 56);                            // (also makes the loop start with both loads retired)
+        if (!last) return false;
+        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+        u32 consumed = 64u - (u32)(remaining - 8 * ptr);
         const u32 sh = 32 - tableLog;
         while (i + 4 <= n) {
-            if (consumed > 20) {                   // 4 codes need up to 44 bits
-                if (!lowerValid) break;
-                const u32 k = consumed >> 3;
-                cont = k == 8 ? lower : ((cont << (8 * k)) | (lower >> (64 - 8 * k)));
-                ptr -= k; consumed -= 8 * k;
-                if (ptr >= 8) lower = readLE64(src + ptr - 8); else lowerValid = false;
-            }
             u32 e, word;
             e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word = e & 0xFFu;
             e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 8;
@@ -593,15 +589,26 @@ __device__ __forceinline__ bool huf_decode_stream4(const u16* __restrict__ table
             e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 24;
             *(u32u*)(out + i) = word;
             i += 4;
+            // re-base: container <- bytes [ptr-k, ptr-k+8); first use of the load issued one step ago
+            const u64 lower = lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0);     // below the stream start: zeros
+            const u32 k = consumed >> 3;                               // 0..6 (consumed <= 7 + 44)
+            cont = (cont << (8 * k)) | (k ? (lower >> (64 - 8 * k)) : 0);
+            ptr -= (s32)k; consumed -= 8 * k;
+            lp = ptr - 8;
+            raw = readLE64(src + (lp > 0 ? lp : 0));
         }
-        remaining = (s32)(8 * ptr) + 64 - (s32)consumed;
+        remaining = 8 * ptr + 64 - (s32)consumed;
+    } else {
+        const u32 last = src[srcSize - 1];
+        if (!last) return false;
+        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
     }
-    if (i < n) {
+    if (i < n && remaining > 0) {
         BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
         while (i < n) { const u32 e = table[bd.peek(tableLog)]; bd.pos -= (s32)(e >> 8); out[i++] = (u8)e; }
         remaining = bd.pos;
     }
-    return remaining == 0;
+    return i == n && remaining == 0;
 }
 
 // One frame on the 4 lanes of a quad.  Header parsing is done redundantly by the 4 lanes (same loads, same values, so

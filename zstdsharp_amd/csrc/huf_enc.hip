@@ -32,8 +32,13 @@ struct HufBuildLds {
     // FSE scratch for the weights (alphabet 0..12, tableLog <= 6)
     u32 wcount[13]; s16 wnorm[13]; u16 wstate[64]; SymTT wtt[13]; u16 wcumul[15]; u8 wsym[64];
     u32 sampleMax[2];
-    int qsStack[192];
+    int qsStack[26][64];        // one explicit quicksort stack per log2 bucket (buckets are sorted by separate lanes)
+    u32 rankCnt[13][4];
+    u32 valPerRank[13];
+    u32 streamBits[4];
+    u32 sh[8];                  // decisions shared by the workgroup: see enum below
 };
+enum { kShCompressed = 0, kShMaxSV, kShRle, kShRleByte, kShHuffLog, kShNonNull, kShRoot, kShHSize };
 
 // ---- HUF_sort (U/HufCompress.cs:520-680): bucket sort by count, quicksort inside the log2 buckets ----
 __device__ __forceinline__ u32 huf_get_index(u32 count) { return count < 165 ? count : highbit32(count) + 158; }
@@ -76,7 +81,8 @@ __device__ inline void huf_quick_sort(Node* a, int low0, int high0, int* stack)
     }
 }
 
-__device__ inline void huf_sort(HufBuildLds& L, u32 maxSV)
+// bucket placement (serial, one lane); the log2 buckets are then sorted by huf_sort_bucket on separate lanes
+__device__ inline void huf_sort_place(HufBuildLds& L, u32 maxSV)
 {
     Node* huffNode = L.nodes + 1;
     const u32 maxSV1 = maxSV + 1;
@@ -87,14 +93,16 @@ __device__ inline void huf_sort(HufBuildLds& L, u32 maxSV)
         const u32 c = L.count[n], r = huf_get_index(c) + 1, pos = L.rankCurr[r]++;
         huffNode[pos].count = c; huffNode[pos].byte = (u8)n;
     }
-    for (u32 n = 165; n < 191; n++) {
-        const u32 bucketSize = L.rankCurr[n] - L.rankBase[n], bucketStart = L.rankBase[n];
-        if (bucketSize > 1) huf_quick_sort(huffNode + bucketStart, 0, (int)bucketSize - 1, L.qsStack);
-    }
+}
+__device__ inline void huf_sort_bucket(HufBuildLds& L, u32 b /* 0..25 */)
+{
+    const u32 n = 165 + b;
+    const u32 bucketSize = L.rankCurr[n] - L.rankBase[n], bucketStart = L.rankBase[n];
+    if (bucketSize > 1) huf_quick_sort(L.nodes + 1 + bucketStart, 0, (int)bucketSize - 1, L.qsStack[b]);
 }
 
 // ---- HUF_buildTree (U/HufCompress.cs:689-738) ----
-__device__ inline int huf_build_tree(Node* huffNode, u32 maxSV)
+__device__ inline int huf_build_tree(Node* huffNode, u32 maxSV, int* rootOut)
 {
     Node* const huffNode0 = huffNode - 1;
     int nonNullRank = (int)maxSV, lowS, lowN, nodeNb = 256, nodeRoot;
@@ -112,9 +120,8 @@ __device__ inline int huf_build_tree(Node* huffNode, u32 maxSV)
         huffNode[n1].parent = huffNode[n2].parent = (u16)nodeNb;
         nodeNb++;
     }
-    huffNode[nodeRoot].nbBits = 0;
-    for (int n = nodeRoot - 1; n >= 256; n--) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
-    for (int n = 0; n <= nonNullRank; n++) huffNode[n].nbBits = huffNode[huffNode[n].parent].nbBits + 1;
+    // code lengths (the reference's two top-down loops) are computed by the caller, one leaf per lane
+    *rootOut = nodeRoot;
     return nonNullRank;
 }
 
@@ -231,9 +238,11 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     }
     for (u32 i = tid; i < 4 * 256; i += 256) (&L.hist[0][0])[i] = 0;
     for (u32 i = tid; i < 2 * 256; i += 256) (&L.sample[0][0])[i] = 0;
+    for (u32 i = tid; i < 513; i += 256) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
+    L.nbBits[tid] = 0;
     __syncthreads();
     const u32 seg = (litSize + 3) / 4;
-    {   // wave w counts segment w
+    {   // wave w counts segment w (these are also the per-stream histograms that size the four streams)
         const u32 s0 = wave * seg, s1 = (s0 + seg < litSize) ? s0 + seg : litSize;
         for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&L.hist[wave][lit[i]], 1u);
     }
@@ -244,11 +253,7 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
         for (u32 i = lane; i < 4096; i += 64) atomicAdd(&L.sample[wave][sp[i]], 1u);
     }
     __syncthreads();
-    {
-        const u32 cnt = L.hist[0][tid] + L.hist[1][tid] + L.hist[2][tid] + L.hist[3][tid];
-        L.count[tid] = cnt;
-        if (doSample && wave < 2) { /* reduce below */ }
-    }
+    L.count[tid] = L.hist[0][tid] + L.hist[1][tid] + L.hist[2][tid] + L.hist[3][tid];
     if (doSample && wave < 2) {
         u32 mx = 0;
         for (u32 i = lane; i < 256; i += 64) { const u32 v = L.sample[wave][i]; mx = v > mx ? v : mx; }
@@ -256,70 +261,101 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
         if (lane == 0) L.sampleMax[wave] = mx;
     }
     __syncthreads();
-    if (tid != 0) return;
 
-    // ---------------- serial section: one lane ----------------
-    bool compressed = true; u32 rleByte = 0; bool rle = false;
-    if (doSample && L.sampleMax[0] + L.sampleMax[1] <= ((2 * 4096) >> 7) + 4) compressed = false;
-    u32 maxSV = 255, largest = 0;
-    if (compressed) {
-        while (!L.count[maxSV]) maxSV--;
-        for (u32 s = 0; s <= maxSV; s++) if (L.count[s] > largest) largest = L.count[s];
-        if (largest == litSize) { rle = true; rleByte = lit[0]; compressed = false; }
-        else if (largest <= (litSize >> 7) + 4) compressed = false;
-    }
-    HufTable* T = tables + c;
     const u32 lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     const u32 single = litSize < 256;
-    u32 hSize = 0, huffLog = 0, cLitSize = 0;
+    HufTable* T = tables + c;
+    if (tid == 0) {       // compressible at all?  (HUF_compress_internal, U/HufCompress.cs:1412-1462)
+        u32 compressed = 1, rle = 0, rleByte = 0, maxSV = 255, largest = 0;
+        if (doSample && L.sampleMax[0] + L.sampleMax[1] <= ((2 * 4096) >> 7) + 4) compressed = 0;
+        if (compressed) {
+            while (!L.count[maxSV]) maxSV--;
+            for (u32 s = 0; s <= maxSV; s++) if (L.count[s] > largest) largest = L.count[s];
+            if (largest == litSize) { rle = 1; rleByte = lit[0]; compressed = 0; }
+            else if (largest <= (litSize >> 7) + 4) compressed = 0;
+        }
+        L.sh[kShCompressed] = compressed; L.sh[kShMaxSV] = maxSV; L.sh[kShRle] = rle; L.sh[kShRleByte] = rleByte;
+        if (compressed) huf_sort_place(L, maxSV);
+    }
+    __syncthreads();
+    const u32 maxSV = L.sh[kShMaxSV];
+    if (L.sh[kShCompressed]) {
+        if (tid < 26) huf_sort_bucket(L, tid);                 // HUF_sort's per-bucket quicksorts, one bucket per lane
+        __syncthreads();
+        Node* huffNode = L.nodes + 1;
+        if (tid == 0) { int root = 0; L.sh[kShNonNull] = (u32)huf_build_tree(huffNode, maxSV, &root); L.sh[kShRoot] = (u32)root; }
+        __syncthreads();
+        {   // depth of every leaf = number of parent links up to the root (HUF_buildTree's nbBits loops)
+            const u32 nonNull = L.sh[kShNonNull], root = L.sh[kShRoot];
+            if (tid <= nonNull) { u32 node = tid, d = 0; while (node != root) { node = huffNode[node].parent; d++; } huffNode[tid].nbBits = (u8)d; }
+        }
+        __syncthreads();
+        if (tid == 0) {
+            u32 huffLog = fse_optimal_table_log(11, litSize, maxSV, 1);
+            const u32 nonNullRank = L.sh[kShNonNull];
+            huffLog = huf_set_max_height(huffNode, nonNullRank, huffLog);
+            u16 nbPerRank[13];
+            for (int i = 0; i < 13; i++) nbPerRank[i] = 0;
+            for (u32 n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
+            { u16 mn = 0; for (int n = (int)huffLog; n > 0; n--) { L.valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
+            L.valPerRank[0] = 0;
+            L.sh[kShHuffLog] = huffLog;
+        }
+        __syncthreads();
+        const u32 huffLog = L.sh[kShHuffLog];
+        if (tid <= maxSV) L.nbBits[huffNode[tid].byte] = huffNode[tid].nbBits;        // HUF_buildCTableFromTree
+        __syncthreads();
+        {   // canonical codes: symbols of one length get consecutive values in symbol order (U/HufCompress.cs:766-785)
+            const u32 nb = tid <= maxSV ? L.nbBits[tid] : 0;
+            u32 pre = 0;
+            for (u32 r = 1; r <= 12; r++) {
+                const u64 b = ballot(nb == r);
+                if (lane == 0) L.rankCnt[r][wave] = popc64(b);
+                if (nb == r) pre = popc64(b & lanemask_lt());
+            }
+            __syncthreads();
+            u32 code = 0;
+            if (nb) { code = L.valPerRank[nb] + pre; for (u32 w = 0; w < wave; w++) code += L.rankCnt[nb][w]; }
+            T->nbBits[tid] = (u8)nb; T->code[tid] = (u16)code;
+            if (tid < maxSV) L.weights[tid] = nb ? (u8)(huffLog + 1 - nb) : 0;             // HUF_writeCTable_wksp's bitsToWeight
+            // stream sizes = sum(count x nbBits) per segment (HUF_compress1X_usingCTable_internal + HUF_closeCStream)
+            u32 bits = 0;
+            for (u32 s = lane; s < 256; s += 64) bits += L.hist[wave][s] * L.nbBits[s];
+            bits = wave_sum(bits);
+            if (lane == 0) L.streamBits[wave] = bits;
+        }
+        __syncthreads();
+    }
+    if (tid != 0) return;
+
+    // ---------------- remaining serial section: tree description + decisions ----------------
+    bool compressed = L.sh[kShCompressed] != 0;
+    const bool rle = L.sh[kShRle] != 0;
+    u32 hSize = 0, cLitSize = 0;
     u32 streamSize[4] = { 0, 0, 0, 0 };
     if (compressed) {
-        huffLog = fse_optimal_table_log(11, litSize, maxSV, 1);
-        Node* huffNode = L.nodes + 1;
-        for (u32 i = 0; i < 513; i++) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
-        huf_sort(L, maxSV);
-        const int nonNullRank = huf_build_tree(huffNode, maxSV);
-        huffLog = huf_set_max_height(huffNode, (u32)nonNullRank, huffLog);
-        // HUF_buildCTableFromTree
-        u16 nbPerRank[13], valPerRank[13];
-        for (int i = 0; i < 13; i++) { nbPerRank[i] = 0; valPerRank[i] = 0; }
-        for (int n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
-        { u16 mn = 0; for (int n = (int)huffLog; n > 0; n--) { valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
-        for (u32 n = 0; n < 256; n++) L.nbBits[n] = 0;
-        for (u32 n = 0; n <= maxSV; n++) L.nbBits[huffNode[n].byte] = huffNode[n].nbBits;
-        for (u32 n = 0; n < 256; n++) { T->nbBits[n] = L.nbBits[n]; T->code[n] = (n <= maxSV) ? valPerRank[L.nbBits[n]]++ : 0; }
-        T->maxSV = maxSV; T->tableLog = huffLog;
-        // HUF_writeCTable_wksp
-        {
-            u8 bitsToWeight[13]; bitsToWeight[0] = 0;
-            for (u32 n = 1; n < huffLog + 1; n++) bitsToWeight[n] = (u8)(huffLog + 1 - n);
-            for (u32 n = 0; n < maxSV; n++) L.weights[n] = bitsToWeight[L.nbBits[n]];
-            const u32 ws = huf_compress_weights(L, T->hdr + 1, maxSV);
-            if (ws > 1 && ws < maxSV / 2) { T->hdr[0] = (u8)ws; hSize = ws + 1; }
-            else if (maxSV > 128) { compressed = false; }     // HUF_writeCTable_wksp fails -> ZSTD_compressLiterals stores raw
-            else {
-                T->hdr[0] = (u8)(128 + (maxSV - 1));
-                L.weights[maxSV] = 0;
-                for (u32 n = 0; n < maxSV; n += 2) T->hdr[(n / 2) + 1] = (u8)((L.weights[n] << 4) + L.weights[n + 1]);
-                hSize = ((maxSV + 1) / 2) + 1;
-            }
+        T->maxSV = maxSV; T->tableLog = L.sh[kShHuffLog];
+        const u32 ws = huf_compress_weights(L, T->hdr + 1, maxSV);
+        if (ws > 1 && ws < maxSV / 2) { T->hdr[0] = (u8)ws; hSize = ws + 1; }
+        else if (maxSV > 128) { compressed = false; }     // HUF_writeCTable_wksp fails -> ZSTD_compressLiterals stores raw
+        else {
+            T->hdr[0] = (u8)(128 + (maxSV - 1));
+            L.weights[maxSV] = 0;
+            for (u32 n = 0; n < maxSV; n += 2) T->hdr[(n / 2) + 1] = (u8)((L.weights[n] << 4) + L.weights[n + 1]);
+            hSize = ((maxSV + 1) / 2) + 1;
         }
         if (compressed && hSize + 12 >= litSize) compressed = false;
     }
     if (compressed) {
-        // stream sizes = sum(count x nbBits) + end mark, per segment (HUF_compress1X_usingCTable_internal + HUF_closeCStream)
         if (single) {
-            u64 bits = 0;
-            for (u32 s = 0; s <= maxSV; s++) bits += (u64)L.count[s] * L.nbBits[s];
-            streamSize[0] = (u32)(bits >> 3) + 1;
+            const u32 bits = L.streamBits[0] + L.streamBits[1] + L.streamBits[2] + L.streamBits[3];
+            streamSize[0] = (bits >> 3) + 1;
             cLitSize = hSize + streamSize[0];
         } else {
             if (litSize < 12) compressed = false;
             cLitSize = hSize + 6;
             for (u32 w = 0; w < 4 && compressed; w++) {
-                u64 bits = 0;
-                for (u32 s = 0; s <= maxSV; s++) bits += (u64)L.hist[w][s] * L.nbBits[s];
-                streamSize[w] = (u32)(bits >> 3) + 1;
+                streamSize[w] = (L.streamBits[w] >> 3) + 1;
                 if (streamSize[w] > 65535) compressed = false;    // (a zero-length stream cannot occur: the end mark is a byte)
                 cLitSize += streamSize[w];
             }
@@ -332,7 +368,7 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
         for (int w = 0; w < 4; w++) m.streamSize[w] = streamSize[w];
         m.litSectionSize = lhSize + cLitSize;
     } else if (rle) {
-        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = rleByte;
+        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = L.sh[kShRleByte];
     } else {
         m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize;
     }
