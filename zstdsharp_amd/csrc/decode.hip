@@ -581,22 +581,38 @@ __device__ __forceinline__ bool huf_decode_stream4(const u16* __restrict__ table
         remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
         u32 consumed = 64u - (u32)(remaining - 8 * ptr);
         const u32 sh = 32 - tableLog;
-        while (i + 4 <= n) {
-            u32 e, word;
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word = e & 0xFFu;
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 8;
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 16;
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 24;
-            *(u32u*)(out + i) = word;
-            i += 4;
-            // re-base: container <- bytes [ptr-k, ptr-k+8); first use of the load issued one step ago
-            const u64 lower = lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0);     // below the stream start: zeros
-            const u32 k = consumed >> 3;                               // 0..6 (consumed <= 7 + 44)
-            cont = (cont << (8 * k)) | (k ? (lower >> (64 - 8 * k)) : 0);
-            ptr -= (s32)k; consumed -= 8 * k;
-            lp = ptr - 8;
-            raw = readLE64(src + (lp > 0 ? lp : 0));
+        // one step = 4 symbols -> one dword, then re-base the container and prefetch the next 8 bytes below it
+#define ZMI_HUF_STEP(word)                                                                                         \
+        {                                                                                                           \
+            u32 e;                                                                                                  \
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word = e & 0xFFu;                 \
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 8;         \
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 16;        \
+            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 24;        \
+            const u64 lower = lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0);                            \
+            const u32 k = consumed >> 3;                                                                            \
+            cont = (cont << (8 * k)) | (k ? (lower >> (64 - 8 * k)) : 0);                                           \
+            ptr -= (s32)k; consumed -= 8 * k;                                                                       \
+            lp = ptr - 8;                                                                                           \
+            raw = readLE64(src + (lp > 0 ? lp : 0));                                                                \
         }
+        // 8 steps per store: vmcnt orders loads and stores together, so every store sits in front of the next
+        // prefetch wait; 32 symbols per (2 x 16 B) store keeps that exposure to once per 32 symbols
+        while (i + 32 <= n) {
+            u32 w0, w1, w2, w3, w4, w5, w6, w7;
+            ZMI_HUF_STEP(w0) ZMI_HUF_STEP(w1) ZMI_HUF_STEP(w2) ZMI_HUF_STEP(w3)
+            ZMI_HUF_STEP(w4) ZMI_HUF_STEP(w5) ZMI_HUF_STEP(w6) ZMI_HUF_STEP(w7)
+            u32u* o = (u32u*)(out + i);
+            o[0] = w0; o[1] = w1; o[2] = w2; o[3] = w3; o[4] = w4; o[5] = w5; o[6] = w6; o[7] = w7;
+            i += 32;
+        }
+        while (i + 4 <= n) {
+            u32 w;
+            ZMI_HUF_STEP(w)
+            *(u32u*)(out + i) = w;
+            i += 4;
+        }
+#undef ZMI_HUF_STEP
         remaining = 8 * ptr + 64 - (s32)consumed;
     } else {
         const u32 last = src[srcSize - 1];
