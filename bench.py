@@ -105,6 +105,7 @@ def main():
         base = datagen.text_like(64 << 20, 7 + rank)
         src = torch.from_numpy(np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()).to(dev)
         workload = f"{args.size_mib} MiB synthetic text (declared stand-in for Silesia dickens, absent offline), level 1, 64 KiB chunks"
+    torch.cuda.synchronize()          # the library runs on its own stream: the input must be complete before the first call
     cap = lib.ZSTD_compressBound(n)
     dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
     back = torch.empty(n, dtype=torch.uint8, device=dev)

@@ -1,12 +1,13 @@
 /*
- * oracle/zso_enc.c — CPU oracle: zstd frame encoder, levels 1-2 ("fast" strategy) plus the
- * strategy-independent entropy stage.  TEST INFRASTRUCTURE ONLY (see zso_common.h).
+ * oracle/zso_enc.c — CPU oracle: zstd frame encoder for the "fast" and "doubleFast" strategies (levels 1-4)
+ * plus the strategy-independent entropy stage.  TEST INFRASTRUCTURE ONLY (see zso_common.h).
  * Restates, in plain C, the compress path of the reference:
  *
  *   level -> cParams          U/ZstdCompress.cs:7891-7927, 2023-2094 ; U/Clevels.cs:10,243,476,709
  *   frame header / epilogue   U/ZstdCompress.cs:4817-4929, 5598-5656
  *   block loop                U/ZstdCompress.cs:4690-4815, 4528-4582, 3432-3530
  *   fast match finder         U/ZstdFast.cs:96-288 ; hashes U/ZstdCompressInternal.cs:340-434
+ *   doubleFast match finder   U/ZstdDoubleFast.cs:51-247
  *   seqStore / codes          U/ZstdCompressInternal.cs:20-38, 204-246 ; U/ZstdCompress.cs:3069-3098
  *   literals section          U/ZstdCompressLiterals.cs:8-185
  *   Huffman                   U/Hist.cs ; U/HufCompress.cs:40-235, 377-823, 989-1355, 1360-1543
@@ -900,6 +901,7 @@ typedef struct {
     const u8* base;            /* index i <-> base + i ; the first source byte has index 2 (U/ZstdCompressInternal.cs:723-732) */
     u32 dictLimit, lowLimit;
     u32* hashTable;
+    u32* chainTable;           /* doubleFast: the short-match table (1 << chainLog) */
 } zso_mstate;
 
 static u32 ms_lowestPrefixIndex(const zso_mstate* ms, u32 curr, u32 windowLog)
@@ -989,6 +991,100 @@ static size_t zso_compressBlock_fast(zso_mstate* ms, zso_seqstore* ss, u32 rep[3
     return (size_t)(iend - anchor);
 }
 
+
+/* ZSTD_compressBlock_doubleFast_noDict_generic, U/ZstdDoubleFast.cs:51-247.  Returns the trailing-literals size. */
+static size_t zso_compressBlock_doubleFast(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize)
+{
+    u32* const hashLong = ms->hashTable; u32 const hBitsL = ms->cp.hashLog;
+    u32* const hashSmall = ms->chainTable; u32 const hBitsS = ms->cp.chainLog;
+    u32 const mls = ms->cp.minMatch;
+    const u8* const base = ms->base; const u8* const istart = src; const u8* anchor = istart;
+    u32 const endIndex = (u32)((size_t)(istart - base) + srcSize);
+    u32 const prefixLowestIndex = ms_lowestPrefixIndex(ms, endIndex, ms->cp.windowLog);
+    const u8* const prefixLowest = base + prefixLowestIndex;
+    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8;
+    u32 offset_1 = rep[0], offset_2 = rep[1], offsetSaved = 0;
+    size_t mLength; u32 offset = 0, curr = 0;
+    size_t const kStepIncr = 1 << 8;
+    const u8* nextStep; size_t step; size_t hl0, hl1; u32 idxl0, idxl1;
+    const u8 *matchl0, *matchs0, *matchl1; const u8* ip = istart; const u8* ip1;
+    if (srcSize < 8) return srcSize;
+    ip += ((ip - prefixLowest) == 0);
+    {   u32 const current = (u32)(ip - base), windowLow = ms_lowestPrefixIndex(ms, current, ms->cp.windowLog), maxRep = current - windowLow;
+        if (offset_2 > maxRep) { offsetSaved = offset_2; offset_2 = 0; }
+        if (offset_1 > maxRep) { offsetSaved = offset_1; offset_1 = 0; }
+    }
+    for (;;) {
+        int how = 0;    /* 1 = repcode (already stored), 2 = long at ip, 3 = search-next-long */
+        step = 1; nextStep = ip + kStepIncr; ip1 = ip + step;
+        if (ip1 > ilimit) break;
+        hl0 = zso_hashPtr(ip, hBitsL, 8); idxl0 = hashLong[hl0]; matchl0 = base + idxl0;
+        do {
+            size_t const hs0 = zso_hashPtr(ip, hBitsS, mls);
+            u32 const idxs0 = hashSmall[hs0];
+            curr = (u32)(ip - base); matchs0 = base + idxs0;
+            hashLong[hl0] = hashSmall[hs0] = curr;
+            if (offset_1 > 0 && zso_readLE32(ip + 1 - offset_1) == zso_readLE32(ip + 1)) {
+                mLength = zso_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
+                ip++;
+                zso_storeSeq(ss, (size_t)(ip - anchor), anchor, 0, mLength - 3);
+                how = 1; break;
+            }
+            hl1 = zso_hashPtr(ip1, hBitsL, 8);
+            if (idxl0 > prefixLowestIndex && zso_readLE64(matchl0) == zso_readLE64(ip)) {
+                mLength = zso_count(ip + 8, matchl0 + 8, iend) + 8;
+                offset = (u32)(ip - matchl0);
+                while (ip > anchor && matchl0 > prefixLowest && ip[-1] == matchl0[-1]) { ip--; matchl0--; mLength++; }
+                how = 2; break;
+            }
+            idxl1 = hashLong[hl1]; matchl1 = base + idxl1;
+            if (idxs0 > prefixLowestIndex && zso_readLE32(matchs0) == zso_readLE32(ip)) { how = 3; break; }
+            if (ip1 >= nextStep) { step++; nextStep += kStepIncr; }
+            ip = ip1; ip1 += step;
+            hl0 = hl1; idxl0 = idxl1; matchl0 = matchl1;
+        } while (ip1 <= ilimit);
+        if (!how) break;
+        if (how == 3) {         /* _search_next_long */
+            if (idxl1 > prefixLowestIndex && zso_readLE64(matchl1) == zso_readLE64(ip1)) {
+                ip = ip1;
+                mLength = zso_count(ip + 8, matchl1 + 8, iend) + 8;
+                offset = (u32)(ip - matchl1);
+                while (ip > anchor && matchl1 > prefixLowest && ip[-1] == matchl1[-1]) { ip--; matchl1--; mLength++; }
+            } else {
+                mLength = zso_count(ip + 4, matchs0 + 4, iend) + 4;
+                offset = (u32)(ip - matchs0);
+                while (ip > anchor && matchs0 > prefixLowest && ip[-1] == matchs0[-1]) { ip--; matchs0--; mLength++; }
+            }
+        }
+        if (how != 1) {         /* _match_found */
+            offset_2 = offset_1; offset_1 = offset;
+            if (step < 4) hashLong[hl1] = (u32)(ip1 - base);
+            zso_storeSeq(ss, (size_t)(ip - anchor), anchor, offset + 2, mLength - 3);
+        }
+        /* _match_stored */
+        ip += mLength; anchor = ip;
+        if (ip <= ilimit) {
+            {   u32 const indexToInsert = curr + 2;
+                hashLong[zso_hashPtr(base + indexToInsert, hBitsL, 8)] = indexToInsert;
+                hashLong[zso_hashPtr(ip - 2, hBitsL, 8)] = (u32)(ip - 2 - base);
+                hashSmall[zso_hashPtr(base + indexToInsert, hBitsS, mls)] = indexToInsert;
+                hashSmall[zso_hashPtr(ip - 1, hBitsS, mls)] = (u32)(ip - 1 - base);
+            }
+            while (ip <= ilimit && offset_2 > 0 && zso_readLE32(ip) == zso_readLE32(ip - offset_2)) {
+                size_t const rLength = zso_count(ip + 4, ip + 4 - offset_2, iend) + 4;
+                u32 const tmpOff = offset_2; offset_2 = offset_1; offset_1 = tmpOff;
+                hashSmall[zso_hashPtr(ip, hBitsS, mls)] = (u32)(ip - base);
+                hashLong[zso_hashPtr(ip, hBitsL, 8)] = (u32)(ip - base);
+                zso_storeSeq(ss, 0, anchor, 0, rLength - 3);
+                ip += rLength; anchor = ip;
+            }
+        }
+    }
+    rep[0] = offset_1 ? offset_1 : offsetSaved;
+    rep[1] = offset_2 ? offset_2 : offsetSaved;
+    return (size_t)(iend - anchor);
+}
+
 /* ------------------------------------------------------------------ */
 /*  frame                                                              */
 /* ------------------------------------------------------------------ */
@@ -1027,7 +1123,8 @@ static void seqstore_reset(zso_seqstore* ss) { ss->nbSeq = 0; ss->litSize = 0; s
 
 static size_t zso_blockCompressor(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize)
 {
-    /* only the "fast" strategy is restated so far; other strategies are declared unpinned by the callers */
+    /* fast and doubleFast are restated; greedy/lazy are refused by the callers, never substituted */
+    if (ms->cp.strategy == ZSO_dfast) return zso_compressBlock_doubleFast(ms, ss, rep, src, srcSize);
     return zso_compressBlock_fast(ms, ss, rep, src, srcSize);
 }
 
@@ -1039,13 +1136,14 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
     zso_mstate ms; zso_seqstore ss; zso_bstate *prev, *next; int isFirstBlock = 1, wroteBlock = 0;
     int const disableLit = (cp.strategy == ZSO_fast) && (cp.targetLength > 0);
     if (blockSize > ZSO_BLOCKSIZE_MAX) blockSize = ZSO_BLOCKSIZE_MAX;
-    if (cp.strategy != ZSO_fast) return ZSO_ERR(parameter_unsupported);   /* not restated yet: say so, never substitute */
+    if (cp.strategy != ZSO_fast && cp.strategy != ZSO_dfast) return ZSO_ERR(parameter_unsupported);   /* not restated yet: say so, never substitute */
     {   size_t const h = zso_writeFrameHeader(op, dstCapacity, cp.windowLog, srcSize, checksumFlag);
         if (zso_isError(h)) return h;
         op += h; dstCapacity -= h;
     }
     ms.cp = cp; ms.base = ip - 2; ms.dictLimit = ms.lowLimit = 2;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
+    ms.chainTable = (u32*)calloc((size_t)1 << cp.chainLog, sizeof(u32));
     seqstore_alloc(&ss, blockSize);
     prev = (zso_bstate*)malloc(sizeof *prev); next = (zso_bstate*)malloc(sizeof *next);
     bstate_reset(prev); bstate_reset(next);
@@ -1101,7 +1199,7 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
     }
     result = (size_t)(op - ostart);
 done:
-    free(ms.hashTable); seqstore_free(&ss); free(prev); free(next);
+    free(ms.hashTable); free(ms.chainTable); seqstore_free(&ss); free(prev); free(next);
     return result;
 }
 
@@ -1127,6 +1225,7 @@ size_t zso_block_sequences(zso_seq* seqs, size_t seqCap, u8* lits, size_t* litSi
     zso_mstate ms; zso_seqstore ss; u32 rep[3] = { 1, 4, 8 }; size_t lastLL, n;
     ms.cp = cp; ms.base = (const u8*)src - 2; ms.dictLimit = ms.lowLimit = 2;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
+    ms.chainTable = (u32*)calloc((size_t)1 << cp.chainLog, sizeof(u32));
     seqstore_alloc(&ss, srcSize + 8);
     lastLL = srcSize < 8 ? srcSize : zso_blockCompressor(&ms, &ss, rep, (const u8*)src, srcSize);
     memcpy(ss.lit + ss.litSize, (const u8*)src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
@@ -1134,7 +1233,7 @@ size_t zso_block_sequences(zso_seq* seqs, size_t seqCap, u8* lits, size_t* litSi
     memcpy(seqs, ss.seqs, n * sizeof(zso_seq));
     memcpy(lits, ss.lit, ss.litSize); *litSizePtr = ss.litSize;
     n = ss.nbSeq;
-    free(ms.hashTable); seqstore_free(&ss);
+    free(ms.hashTable); free(ms.chainTable); seqstore_free(&ss);
     return n;
 }
 

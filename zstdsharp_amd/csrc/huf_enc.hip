@@ -113,10 +113,15 @@ __device__ inline int huf_build_tree(Node* huffNode, u32 maxSV, int* rootOut)
     nodeNb++; lowS -= 2;
     for (int n = nodeNb; n <= nodeRoot; n++) huffNode[n].count = 1u << 30;
     huffNode0[0].count = 1u << 31;
+    // two-queue merge; the heads of both queues are kept in registers so that each pick costs one LDS read
+    u32 cS = huffNode[lowS].count, cN = huffNode[lowN].count;
     while (nodeNb <= nodeRoot) {
-        const int n1 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
-        const int n2 = (huffNode[lowS].count < huffNode[lowN].count) ? lowS-- : lowN++;
-        huffNode[nodeNb].count = huffNode[n1].count + huffNode[n2].count;
+        int n1, n2; u32 c1, c2;
+        // (a head equal to nodeNb reads the 1<<30 placeholder, exactly as the reference's second comparison does)
+        if (cS < cN) { n1 = lowS--; c1 = cS; cS = huffNode[lowS].count; } else { n1 = lowN++; c1 = cN; cN = huffNode[lowN].count; }
+        if (cS < cN) { n2 = lowS--; c2 = cS; cS = huffNode[lowS].count; } else { n2 = lowN++; c2 = cN; cN = huffNode[lowN].count; }
+        huffNode[nodeNb].count = c1 + c2;
+        if (lowN == nodeNb) cN = c1 + c2;          // the node just created is the next head of the node queue
         huffNode[n1].parent = huffNode[n2].parent = (u16)nodeNb;
         nodeNb++;
     }

@@ -21,18 +21,22 @@
 namespace zmi {
 
 constexpr u32 kHashLog  = 13;            // the reference's hashLog for level 1 at <= 128 KiB (U/Clevels.cs:488)
-constexpr u32 kTile     = 1024;          // positions per tile == threads per workgroup
+constexpr u32 kTile     = 1024;          // threads per workgroup
+constexpr u32 kPPT      = 4;             // positions per thread per tile (independent probes in flight per lane)
+constexpr u32 kTilePos  = kTile * kPPT;  // positions per tile
+constexpr u32 kTileLog  = 12;            // log2(kTilePos)
+static_assert((1u << kTileLog) == kTilePos, "tile geometry");
 constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; the selecting wave extends the rest
 constexpr u32 kInPad    = 64;
 
 struct LzLds {
     u8  in[kChunkSize + kInPad];
     u32 table[1u << kHashLog];           // position+1 of the latest occurrence of the hash in EARLIER tiles; 0 = empty
-    u32 first[1u << kHashLog];           // first occurrence of the hash inside the CURRENT tile: ((63-tile) << 10) | index
-    u16 tileOff[kTile];
-    u8  tileLen[kTile];
+    u32 first[1u << kHashLog];           // first occurrence of the hash inside the CURRENT tile: ((15-tile) << 12) | index
+    u16 tileOff[kTilePos];
+    u8  tileLen[kTilePos];
     u32 cov[kChunkSize / 32];            // bit p set <=> byte p is covered by a selected match
-    u64 tileMask[16];                    // per 64-position group of the current tile: lanes that hold a match
+    u64 tileMask[kTilePos / 64];         // per 64-position group of the current tile: lanes that hold a match
     u32 waveCnt[2][16];
     u32 nbSeq, anchorEnd;
 };
@@ -46,7 +50,7 @@ __device__ __forceinline__ void walk_tile(LzLds& L, u32 n, u32 tileStart, Seq* _
 {
     const u32 lane = lane_id();
     // groups of this tile that hold at least one match: the walker only visits those
-    u64 groups = ballot(lane < kTile / 64 && L.tileMask[lane & 15] != 0);
+    u64 groups = ballot(lane < kTilePos / 64 && L.tileMask[lane % (kTilePos / 64)] != 0);
     while (groups) {
         const u32 g = ctz64(groups);
         groups &= groups - 1;
@@ -155,41 +159,52 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
 
     // Matches may start where 8 bytes are still readable (the reference stops at iend-8, ZstdFast.cs:110).
-    const u32 nTiles = (n + kTile - 1) / kTile;
+    const u32 nTiles = (n + kTilePos - 1) / kTilePos;
     for (u32 t = 0; t < nTiles; ++t) {
-        const u32 p = t * kTile + tid;
-        const bool valid = p + 8 <= n;
-        u64 w = 0; u32 h = 0, cand = 0;
-        const u32 stamp = (63u - t) << 10;
-        if (valid) { w = readLE64(L.in + p); h = hash6(w); cand = L.table[h]; atomicMin(&L.first[h], stamp | tid); }
-        __syncthreads();                       // every probe of this tile precedes every insert of this tile
-        if (valid) {
-            atomicMax(&L.table[h], p + 1);
-            const u32 f = L.first[h];          // same-tile first occurrence: nearer than anything in the cross-tile table
-            if ((f >> 10) == (63u - t) && (f & 1023u) < tid) cand = t * kTile + (f & 1023u) + 1;
+        const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
+        u64 w[kPPT]; u32 h[kPPT], cand[kPPT]; bool valid[kPPT];
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 q = j * kTile + tid, p = t * kTilePos + q;
+            valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cand[j] = 0;
+            if (valid[j]) { w[j] = readLE64(L.in + p); h[j] = hash6(w[j]); cand[j] = L.table[h[j]]; atomicMin(&L.first[h[j]], stamp | q); }
         }
-        u32 len = 0, off = 0;
-        if (cand) {
-            const u32 cpos = cand - 1;
-            u64 x = w ^ readLE64(L.in + cpos);
-            if ((u32)x == 0) {                 // >= 4 equal bytes, as the reference's MEM_read32 check (ZstdFast.cs:179-191)
-                u32 l = x ? (ctz64(x) >> 3) : 8;
-                if (!x) {
-                    while (l < kLenCap) {
-                        x = readLE64(L.in + p + l) ^ readLE64(L.in + cpos + l);
-                        if (x) { l += ctz64(x) >> 3; break; }
-                        l += 8;
-                    }
-                }
-                if (l > n - p) l = n - p;
-                if (l > kLenCap) l = kLenCap;
-                if (l >= 4) { len = l; off = p - cpos; }
+        __syncthreads();                       // every probe of this tile precedes every insert of this tile
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 q = j * kTile + tid, p = t * kTilePos + q;
+            if (valid[j]) {
+                atomicMax(&L.table[h[j]], p + 1);
+                const u32 f = L.first[h[j]];   // same-tile first occurrence: nearer than anything in the cross-tile table
+                if ((f >> kTileLog) == (stamp >> kTileLog) && (f & (kTilePos - 1)) < q) cand[j] = t * kTilePos + (f & (kTilePos - 1)) + 1;
             }
         }
-        L.tileLen[tid] = (u8)len; L.tileOff[tid] = (u16)off;
-        { const u64 mm = ballot(len != 0); if (lane == 0) L.tileMask[wave] = mm; }
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 q = j * kTile + tid, p = t * kTilePos + q;
+            u32 len = 0, off = 0;
+            if (cand[j]) {
+                const u32 cpos = cand[j] - 1;
+                u64 x = w[j] ^ readLE64(L.in + cpos);
+                if ((u32)x == 0) {             // >= 4 equal bytes, as the reference's MEM_read32 check (ZstdFast.cs:179-191)
+                    u32 l = x ? (ctz64(x) >> 3) : 8;
+                    if (!x) {
+                        while (l < kLenCap) {
+                            x = readLE64(L.in + p + l) ^ readLE64(L.in + cpos + l);
+                            if (x) { l += ctz64(x) >> 3; break; }
+                            l += 8;
+                        }
+                    }
+                    if (l > n - p) l = n - p;
+                    if (l > kLenCap) l = kLenCap;
+                    if (l >= 4) { len = l; off = p - cpos; }
+                }
+            }
+            L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off;
+            { const u64 mm = ballot(len != 0); if (lane == 0) L.tileMask[j * (kTile / 64) + wave] = mm; }
+        }
         __syncthreads();                       // tile arrays and inserts visible
-        if (wave == 0) walk_tile(L, n, t * kTile, seqOut, st);
+        if (wave == 0) walk_tile(L, n, t * kTilePos, seqOut, st);
         // the other 15 waves run ahead into the next tile's probes; they meet wave 0 at that tile's first barrier
     }
     if (tid == 0) { L.nbSeq = st.nbSeq; }
