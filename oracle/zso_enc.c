@@ -1,6 +1,6 @@
 /*
- * oracle/zso_enc.c — CPU oracle: zstd frame encoder for the "fast" and "doubleFast" strategies (levels 1-4)
- * plus the strategy-independent entropy stage.  TEST INFRASTRUCTURE ONLY (see zso_common.h).
+ * oracle/zso_enc.c — CPU oracle: zstd frame encoder for the "fast" and "doubleFast" strategies (levels 1-4), greedy/lazy over the
+ * row-hash match finder (level 5 and the greedy tiers of level 4) plus the strategy-independent entropy stage.  TEST INFRASTRUCTURE ONLY (see zso_common.h).
  * Restates, in plain C, the compress path of the reference:
  *
  *   level -> cParams          U/ZstdCompress.cs:7891-7927, 2023-2094 ; U/Clevels.cs:10,243,476,709
@@ -8,6 +8,7 @@
  *   block loop                U/ZstdCompress.cs:4690-4815, 4528-4582, 3432-3530
  *   fast match finder         U/ZstdFast.cs:96-288 ; hashes U/ZstdCompressInternal.cs:340-434
  *   doubleFast match finder   U/ZstdDoubleFast.cs:51-247
+ *   greedy/lazy + row hash    U/ZstdLazy.cs:788-1309, 1743-2032
  *   seqStore / codes          U/ZstdCompressInternal.cs:20-38, 204-246 ; U/ZstdCompress.cs:3069-3098
  *   literals section          U/ZstdCompressLiterals.cs:8-185
  *   Huffman                   U/Hist.cs ; U/HufCompress.cs:40-235, 377-823, 989-1355, 1360-1543
@@ -902,6 +903,8 @@ typedef struct {
     u32 dictLimit, lowLimit;
     u32* hashTable;
     u32* chainTable;           /* doubleFast: the short-match table (1 << chainLog) */
+    u16* tagTable;             /* row-hash match finder: 1 << hashLog u16 (head byte + tags per row) */
+    u32 rowHashLog, nextToUpdate, hashCache[8];
 } zso_mstate;
 
 static u32 ms_lowestPrefixIndex(const zso_mstate* ms, u32 curr, u32 windowLog)
@@ -1085,6 +1088,176 @@ static size_t zso_compressBlock_doubleFast(zso_mstate* ms, zso_seqstore* ss, u32
     return (size_t)(iend - anchor);
 }
 
+
+/* ------------------------------------------------------------------ */
+/*  greedy / lazy parse over the row-hash match finder (levels 4-5+)   */
+/* ------------------------------------------------------------------ */
+/* U/ZstdLazy.cs:788-1309 (row helpers + ZSTD_RowFindBestMatch, noDict), :1743-2032 (ZSTD_compressBlock_lazy_generic). */
+#define ZSO_ROW_TAG_OFFSET 16
+static u32 row_nextIndex(u8* tagRow, u32 rowMask) { u32 const next = (u32)(*tagRow - 1) & rowMask; *tagRow = (u8)next; return next; }
+static u32 row_hash(const zso_mstate* ms, u32 idx, u32 mls) { return (u32)zso_hashPtr(ms->base + idx, ms->rowHashLog + 8, mls); }
+static void row_fillHashCache(zso_mstate* ms, u32 mls, u32 idx, const u8* iLimit)
+{
+    u32 const maxElems = (ms->base + idx) > iLimit ? 0 : (u32)(iLimit - (ms->base + idx) + 1);
+    u32 const lim = idx + (8 < maxElems ? 8 : maxElems);
+    for (; idx < lim; ++idx) ms->hashCache[idx & 7] = row_hash(ms, idx, mls);
+}
+static u32 row_nextCachedHash(zso_mstate* ms, u32 idx, u32 mls)
+{
+    u32 const newHash = row_hash(ms, idx + 8, mls);
+    u32 const hash = ms->hashCache[idx & 7];
+    ms->hashCache[idx & 7] = newHash;
+    return hash;
+}
+static void row_update_impl(zso_mstate* ms, u32 start, u32 end, u32 mls, u32 rowLog, u32 rowMask, int useCache)
+{
+    for (; start < end; ++start) {
+        u32 const hash = useCache ? row_nextCachedHash(ms, start, mls) : row_hash(ms, start, mls);
+        u32 const relRow = (hash >> 8) << rowLog;
+        u32* const row = ms->hashTable + relRow;
+        u8* const tagRow = (u8*)(ms->tagTable + relRow);
+        u32 const pos = row_nextIndex(tagRow, rowMask);
+        tagRow[pos + ZSO_ROW_TAG_OFFSET] = (u8)hash;
+        row[pos] = start;
+    }
+}
+static void row_update(zso_mstate* ms, const u8* ip, u32 mls, u32 rowLog, u32 rowMask, int useCache)
+{
+    u32 idx = ms->nextToUpdate; u32 const target = (u32)(ip - ms->base);
+    if (useCache && target - idx > 384) {
+        row_update_impl(ms, idx, idx + 96, mls, rowLog, rowMask, useCache);
+        idx = target - 32;
+        row_fillHashCache(ms, mls, idx, ip + 1);
+    }
+    row_update_impl(ms, idx, target, mls, rowLog, rowMask, useCache);
+    ms->nextToUpdate = target;
+}
+static u64 row_getMatchMask(const u8* tagRow, u8 tag, u32 head, u32 rowEntries)
+{
+    u64 m = 0; u32 i;
+    for (i = 0; i < rowEntries; i++) if (tagRow[ZSO_ROW_TAG_OFFSET + i] == tag) m |= (u64)1 << i;
+    if (head == 0) return m;
+    if (rowEntries == 64) return (m >> head) | (m << (64 - head));
+    return ((m >> head) | (m << (rowEntries - head))) & (((u64)1 << rowEntries) - 1);
+}
+/* ZSTD_RowFindBestMatch, noDict */
+static size_t row_findBestMatch(zso_mstate* ms, const u8* ip, const u8* iLimit, size_t* offsetPtr, u32 mls, u32 rowLog)
+{
+    const u8* const base = ms->base;
+    u32 const curr = (u32)(ip - base), maxDistance = 1u << ms->cp.windowLog, lowestValid = ms->lowLimit;
+    u32 const lowLimit = (curr - lowestValid > maxDistance) ? curr - maxDistance : lowestValid;
+    u32 const rowEntries = 1u << rowLog, rowMask = rowEntries - 1;
+    u32 const cappedSearchLog = ms->cp.searchLog < rowLog ? ms->cp.searchLog : rowLog;
+    u32 nbAttempts = 1u << cappedSearchLog;
+    size_t ml = 4 - 1;
+    row_update(ms, ip, mls, rowLog, rowMask, 1);
+    {   u32 const hash = row_nextCachedHash(ms, curr, mls);
+        u32 const relRow = (hash >> 8) << rowLog; u8 const tag = (u8)hash;
+        u32* const row = ms->hashTable + relRow; u8* const tagRow = (u8*)(ms->tagTable + relRow);
+        u32 const head = *tagRow & rowMask;
+        u32 matchBuffer[64]; size_t numMatches = 0, currMatch;
+        u64 matches = row_getMatchMask(tagRow, tag, head, rowEntries);
+        for (; matches > 0 && nbAttempts > 0; --nbAttempts, matches &= (matches - 1)) {
+            u32 const matchPos = (head + (u32)__builtin_ctzll(matches)) & rowMask;
+            u32 const matchIndex = row[matchPos];
+            if (matchIndex < lowLimit) break;
+            matchBuffer[numMatches++] = matchIndex;
+        }
+        {   u32 const pos = row_nextIndex(tagRow, rowMask);
+            tagRow[pos + ZSO_ROW_TAG_OFFSET] = tag;
+            row[pos] = ms->nextToUpdate++;
+        }
+        for (currMatch = 0; currMatch < numMatches; ++currMatch) {
+            u32 const matchIndex = matchBuffer[currMatch];
+            const u8* const match = base + matchIndex;
+            size_t currentMl = 0;
+            if (match[ml] == ip[ml]) currentMl = zso_count(ip, match, iLimit);
+            if (currentMl > ml) {
+                ml = currentMl; *offsetPtr = curr - matchIndex + 2;
+                if (ip + currentMl == iLimit) break;
+            }
+        }
+    }
+    return ml;
+}
+/* ZSTD_compressBlock_lazy_generic, noDict + row hash; depth 0 = greedy, 1 = lazy, 2 = lazy2 */
+static size_t zso_compressBlock_lazy_row(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize, u32 depth)
+{
+    const u8* const istart = src; const u8* ip = istart; const u8* anchor = istart;
+    const u8* const iend = istart + srcSize; const u8* const ilimit = iend - 8 - 8;
+    const u8* const base = ms->base;
+    u32 const prefixLowestIndex = ms->dictLimit; const u8* const prefixLowest = base + prefixLowestIndex;
+    u32 offset_1 = rep[0], offset_2 = rep[1], savedOffset = 0;
+    u32 const sl = ms->cp.searchLog, rowLog = sl < 4 ? 4 : (sl > 6 ? 6 : sl);
+    u32 const mls = ms->cp.minMatch < 4 ? 4 : (ms->cp.minMatch > 6 ? 6 : ms->cp.minMatch);
+    if (srcSize < 16) return srcSize;
+    ip += ((ip - prefixLowest) == 0);
+    {   u32 const curr = (u32)(ip - base), windowLow = ms_lowestPrefixIndex(ms, curr, ms->cp.windowLog), maxRep = curr - windowLow;
+        if (offset_2 > maxRep) { savedOffset = offset_2; offset_2 = 0; }
+        if (offset_1 > maxRep) { savedOffset = offset_1; offset_1 = 0; }
+    }
+    row_fillHashCache(ms, mls, ms->nextToUpdate, ilimit);
+    while (ip < ilimit) {
+        size_t matchLength = 0, offset = 0; const u8* start = ip + 1; int storeNow = 0;
+        if (offset_1 > 0 && zso_readLE32(ip + 1 - offset_1) == zso_readLE32(ip + 1)) {
+            matchLength = zso_count(ip + 1 + 4, ip + 1 + 4 - offset_1, iend) + 4;
+            if (depth == 0) storeNow = 1;
+        }
+        if (!storeNow) {
+            {   size_t offsetFound = 999999999;
+                size_t const ml2 = row_findBestMatch(ms, ip, iend, &offsetFound, mls, rowLog);
+                if (ml2 > matchLength) { matchLength = ml2; start = ip; offset = offsetFound; }
+            }
+            if (matchLength < 4) { ip += ((ip - anchor) >> 8) + 1; continue; }
+            if (depth >= 1) {
+                while (ip < ilimit) {
+                    ip++;
+                    if (offset && offset_1 > 0 && zso_readLE32(ip) == zso_readLE32(ip - offset_1)) {
+                        size_t const mlRep = zso_count(ip + 4, ip + 4 - offset_1, iend) + 4;
+                        int const gain2 = (int)(mlRep * 3), gain1 = (int)(matchLength * 3 - zso_highbit32((u32)offset + 1) + 1);
+                        if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offset = 0; start = ip; }
+                    }
+                    {   size_t offset2 = 999999999;
+                        size_t const ml2 = row_findBestMatch(ms, ip, iend, &offset2, mls, rowLog);
+                        int const gain2 = (int)(ml2 * 4 - zso_highbit32((u32)offset2 + 1)), gain1 = (int)(matchLength * 4 - zso_highbit32((u32)offset + 1) + 4);
+                        if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offset = offset2; start = ip; continue; }
+                    }
+                    if (depth == 2 && ip < ilimit) {
+                        ip++;
+                        if (offset && offset_1 > 0 && zso_readLE32(ip) == zso_readLE32(ip - offset_1)) {
+                            size_t const mlRep = zso_count(ip + 4, ip + 4 - offset_1, iend) + 4;
+                            int const gain2 = (int)(mlRep * 4), gain1 = (int)(matchLength * 4 - zso_highbit32((u32)offset + 1) + 1);
+                            if (mlRep >= 4 && gain2 > gain1) { matchLength = mlRep; offset = 0; start = ip; }
+                        }
+                        {   size_t offset2 = 999999999;
+                            size_t const ml2 = row_findBestMatch(ms, ip, iend, &offset2, mls, rowLog);
+                            int const gain2 = (int)(ml2 * 4 - zso_highbit32((u32)offset2 + 1)), gain1 = (int)(matchLength * 4 - zso_highbit32((u32)offset + 1) + 7);
+                            if (ml2 >= 4 && gain2 > gain1) { matchLength = ml2; offset = offset2; start = ip; continue; }
+                        }
+                    }
+                    break;
+                }
+            }
+            if (offset) {       /* catch up */
+                while (start > anchor && start - (offset - 2) > prefixLowest && start[-1] == (start - (offset - 2))[-1]) { start--; matchLength++; }
+                offset_2 = offset_1; offset_1 = (u32)(offset - 2);
+            }
+        }
+        /* _storeSequence */
+        zso_storeSeq(ss, (size_t)(start - anchor), anchor, (u32)offset, matchLength - 3);
+        anchor = ip = start + matchLength;
+        while (ip <= ilimit && offset_2 > 0 && zso_readLE32(ip) == zso_readLE32(ip - offset_2)) {
+            matchLength = zso_count(ip + 4, ip + 4 - offset_2, iend) + 4;
+            offset = offset_2; offset_2 = offset_1; offset_1 = (u32)offset;
+            zso_storeSeq(ss, 0, anchor, 0, matchLength - 3);
+            ip += matchLength; anchor = ip;
+        }
+    }
+    rep[0] = offset_1 ? offset_1 : savedOffset;
+    rep[1] = offset_2 ? offset_2 : savedOffset;
+    return (size_t)(iend - anchor);
+}
+
 /* ------------------------------------------------------------------ */
 /*  frame                                                              */
 /* ------------------------------------------------------------------ */
@@ -1123,8 +1296,10 @@ static void seqstore_reset(zso_seqstore* ss) { ss->nbSeq = 0; ss->litSize = 0; s
 
 static size_t zso_blockCompressor(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], const u8* src, size_t srcSize)
 {
-    /* fast and doubleFast are restated; greedy/lazy are refused by the callers, never substituted */
+    /* fast, doubleFast and greedy/lazy over the row-hash finder are restated; anything else is refused by the callers */
     if (ms->cp.strategy == ZSO_dfast) return zso_compressBlock_doubleFast(ms, ss, rep, src, srcSize);
+    if (ms->cp.strategy == ZSO_greedy) return zso_compressBlock_lazy_row(ms, ss, rep, src, srcSize, 0);
+    if (ms->cp.strategy == ZSO_lazy) return zso_compressBlock_lazy_row(ms, ss, rep, src, srcSize, 1);
     return zso_compressBlock_fast(ms, ss, rep, src, srcSize);
 }
 
@@ -1136,7 +1311,9 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
     zso_mstate ms; zso_seqstore ss; zso_bstate *prev, *next; int isFirstBlock = 1, wroteBlock = 0;
     int const disableLit = (cp.strategy == ZSO_fast) && (cp.targetLength > 0);
     if (blockSize > ZSO_BLOCKSIZE_MAX) blockSize = ZSO_BLOCKSIZE_MAX;
-    if (cp.strategy != ZSO_fast && cp.strategy != ZSO_dfast) return ZSO_ERR(parameter_unsupported);   /* not restated yet: say so, never substitute */
+    /* greedy/lazy use the row-hash finder only when windowLog > 14 (ZSTD_resolveRowMatchFinderMode, U/ZstdCompress.cs:221-252);
+       the hash-chain finder of the small-window tiers is not restated: say so, never substitute */
+    if (cp.strategy >= ZSO_greedy && cp.windowLog <= 14) return ZSO_ERR(parameter_unsupported);
     {   size_t const h = zso_writeFrameHeader(op, dstCapacity, cp.windowLog, srcSize, checksumFlag);
         if (zso_isError(h)) return h;
         op += h; dstCapacity -= h;
@@ -1144,6 +1321,9 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
     ms.cp = cp; ms.base = ip - 2; ms.dictLimit = ms.lowLimit = 2;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
     ms.chainTable = (u32*)calloc((size_t)1 << cp.chainLog, sizeof(u32));
+    ms.tagTable = (u16*)calloc((size_t)1 << cp.hashLog, sizeof(u16));
+    {   u32 const sl = cp.searchLog, rowLog = sl < 4 ? 4 : (sl > 6 ? 6 : sl); ms.rowHashLog = cp.hashLog - rowLog; }
+    ms.nextToUpdate = 2; memset(ms.hashCache, 0, sizeof ms.hashCache);
     seqstore_alloc(&ss, blockSize);
     prev = (zso_bstate*)malloc(sizeof *prev); next = (zso_bstate*)malloc(sizeof *next);
     bstate_reset(prev); bstate_reset(next);
@@ -1161,11 +1341,15 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
                 if (ms.dictLimit < ms.lowLimit) ms.dictLimit = ms.lowLimit;
             }
         }
+        if (ms.nextToUpdate < ms.lowLimit) ms.nextToUpdate = ms.lowLimit;
         /* ZSTD_compressBlock_internal */
         if (blockSize < 1 + 1 + 1 + 3 + 1) cSize = 0;          /* ZSTD_buildSeqStore: too small, don't even try */
         else {
             size_t lastLL; int i;
             seqstore_reset(&ss);
+            {   u32 const curr = (u32)(ip - ms.base);     /* ZSTD_buildSeqStore: limit catch-up after a long uncompressed stretch */
+                if (curr > ms.nextToUpdate + 384) { u32 const d = curr - ms.nextToUpdate - 384; ms.nextToUpdate = curr - (192 < d ? 192 : d); }
+            }
             for (i = 0; i < 3; i++) next->rep[i] = prev->rep[i];
             lastLL = zso_blockCompressor(&ms, &ss, next->rep, ip, blockSize);
             memcpy(ss.lit + ss.litSize, ip + blockSize - lastLL, lastLL); ss.litSize += lastLL;
@@ -1199,7 +1383,7 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
     }
     result = (size_t)(op - ostart);
 done:
-    free(ms.hashTable); free(ms.chainTable); seqstore_free(&ss); free(prev); free(next);
+    free(ms.hashTable); free(ms.chainTable); free(ms.tagTable); seqstore_free(&ss); free(prev); free(next);
     return result;
 }
 
@@ -1226,6 +1410,9 @@ size_t zso_block_sequences(zso_seq* seqs, size_t seqCap, u8* lits, size_t* litSi
     ms.cp = cp; ms.base = (const u8*)src - 2; ms.dictLimit = ms.lowLimit = 2;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
     ms.chainTable = (u32*)calloc((size_t)1 << cp.chainLog, sizeof(u32));
+    ms.tagTable = (u16*)calloc((size_t)1 << cp.hashLog, sizeof(u16));
+    {   u32 const sl = cp.searchLog, rowLog = sl < 4 ? 4 : (sl > 6 ? 6 : sl); ms.rowHashLog = cp.hashLog - rowLog; }
+    ms.nextToUpdate = 2; memset(ms.hashCache, 0, sizeof ms.hashCache);
     seqstore_alloc(&ss, srcSize + 8);
     lastLL = srcSize < 8 ? srcSize : zso_blockCompressor(&ms, &ss, rep, (const u8*)src, srcSize);
     memcpy(ss.lit + ss.litSize, (const u8*)src + srcSize - lastLL, lastLL); ss.litSize += lastLL;
@@ -1233,7 +1420,7 @@ size_t zso_block_sequences(zso_seq* seqs, size_t seqCap, u8* lits, size_t* litSi
     memcpy(seqs, ss.seqs, n * sizeof(zso_seq));
     memcpy(lits, ss.lit, ss.litSize); *litSizePtr = ss.litSize;
     n = ss.nbSeq;
-    free(ms.hashTable); free(ms.chainTable); seqstore_free(&ss);
+    free(ms.hashTable); free(ms.chainTable); free(ms.tagTable); seqstore_free(&ss);
     return n;
 }
 
