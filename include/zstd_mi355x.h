@@ -91,6 +91,9 @@ size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* dctx, int device);
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* cctx, void* hipStream);
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* dctx, void* hipStream);
 
+/* inputs larger than one pass are compressed pass by pass (default 16384 chunks = 1 GiB, which bounds the HBM workspace) */
+size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* cctx, unsigned chunksPerPass);
+
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
 size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);
 size_t ZSTDMI_decompressDevice(ZSTD_DCtx* dctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);

@@ -243,6 +243,19 @@ def test_device_resident_api_and_large_input(gpu_lib, oracle):
     c.Dispose(); d.Dispose()
 
 
+def test_multi_pass_inputs(gpu_lib, oracle):
+    """Inputs beyond one pass of the HBM workspace are compressed pass by pass; force 3-chunk passes on a 10-chunk input."""
+    data = datagen.gen("mixed", 10 * 65536 + 777, 12)
+    with z.Compressor(1) as c, z.Decompressor() as d:
+        whole = c.Wrap(data)
+        assert gpu_lib.ZSTDMI_CCtx_setPassChunks(c.cctx, 3) == 0
+        comp = c.Wrap(data)
+        assert comp == whole                                   # pass boundaries do not change the stream
+        assert oracle.decompress(comp, len(data)) == data and d.Unwrap(comp) == data
+        ok, _ = c.TryWrap(data, bytearray(len(comp) - 1))      # too small by one byte, detected in the last pass
+        assert ok is False
+
+
 def test_many_contexts_concurrently(gpu_lib):
     """T/ZstdNetTests.cs:498-522: many tasks, each with its own contexts."""
     import concurrent.futures as cf

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ZSTDMI_DCtx_setDevice": (c_size_t, [c_void_p, c_int]),
     "ZSTDMI_CCtx_setStream": (c_size_t, [c_void_p, c_void_p]),
     "ZSTDMI_DCtx_setStream": (c_size_t, [c_void_p, c_void_p]),
+    "ZSTDMI_CCtx_setPassChunks": (c_size_t, [c_void_p, c_uint]),
     "ZSTDMI_compressDevice": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "ZSTDMI_decompressDevice": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "ZSTDMI_CCtx_setProfiling": (c_size_t, [c_void_p, c_int]),

@@ -93,6 +93,7 @@ struct ZSTD_CCtx_s {
     hipStream_t ownStream = nullptr, stream = nullptr;
     DevBuf seqs, lits, meta, tables, slots, offsets, total, stageSrc, stageDst;
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
+    u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
     StageTimer timer;
     float stageMs[kMaxStages] = {}; const char* stageNames[kMaxStages] = {}; int nStages = 0;
 };
@@ -105,7 +106,6 @@ struct ZSTD_DCtx_s {
     StageTimer timer;
 };
 
-static const u32 kPassChunks = 16384;       // 1 GiB of input per pass; bounds the HBM workspace to ~4.2 GiB
 
 static size_t cctx_bind(ZSTD_CCtx* c)
 {
@@ -159,7 +159,7 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         return n;
     }
     const u64 totalChunks = (srcSize + kChunkSize - 1) / kChunkSize;
-    const u32 passChunks = (u32)(totalChunks < kPassChunks ? totalChunks : kPassChunks);
+    const u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = strategy_for_level(c->level);
     size_t produced = 0;
@@ -553,6 +553,7 @@ size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kEr
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* c, unsigned chunks) { if (!c || chunks == 0 || chunks > (1u << 20)) return ZERR(kErrParameterOutOfBound); c->passChunks = chunks; return 0; }
 size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* c, int en) { if (!c) return ZERR(kErrGeneric); c->timer.enabled = en != 0; return 0; }
 size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* d, int en) { if (!d) return ZERR(kErrGeneric); d->timer.enabled = en != 0; return 0; }
 int ZSTDMI_CCtx_getStageTimes(const ZSTD_CCtx* c, float* ms, const char** names, int cap)
