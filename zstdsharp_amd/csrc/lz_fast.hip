@@ -1,132 +1,93 @@
-// lz_fast.hip — level-1 ("fast" strategy) LZ match finder for gfx950: one 1024-thread workgroup per 64 KiB chunk.
+// lz_fast.hip — level-1 ("fast" strategy) LZ match finder + parse for gfx950: one 1024-thread workgroup per 64 KiB chunk.
 //
 // Takes the place of ZSTD_compressBlock_fast_noDict_generic (U/ZstdFast.cs:96-288) + ZSTD_storeSeq
-// (U/ZstdCompressInternal.cs:204-246) for one block.  It is NOT that function's parse: the reference walks
-// the block serially, inserting only the positions it visits; here every position of a 1024-byte tile is
-// hashed (hash6, U/ZstdCompressInternal.cs:380-392), probed and verified by its own lane against the
-// LDS-resident table of all earlier tiles, and wave 0 then performs the greedy left-to-right selection over
-// the tile with ballots.  The produced sequences are therefore valid but not identical to the reference's
-// (SURVEY.md §7 "valid zstd frames, not byte-identical frames"); repcode assignment follows the decoder's
-// history rule (U/ZstdDecompressBlock.cs:2387-2443) so every emitted offBase decodes to the intended offset.
+// (U/ZstdCompressInternal.cs:204-246) for one block.  It is NOT that function's parse: the reference walks the
+// block serially, inserting only the positions it visits.  Here, per 4096-byte tile:
 //
-// Candidates inside the same tile are found through a second table that keeps, per hash, the FIRST position of
-// the current tile (atomicMin with a tile stamp, so it needs no clearing and is order-independent): a lane whose
-// hash was already seen in its own tile matches against that nearer occurrence, which is what catches runs and
-// short-period data.  Both tables are updated with commutative atomics only, so the output is deterministic.
+//   probe    every position is hashed (hash6, U/ZstdCompressInternal.cs:380-392) and probed by its own lane against
+//            two LDS tables — the latest occurrence in EARLIER tiles (atomicMax) and the first occurrence in THIS
+//            tile (atomicMin with a tile stamp, so it needs no clearing) — plus a register-only test for periods
+//            1..4 (runs), then verified and extended up to 32 bytes (the reference's 4-byte check, ZstdFast.cs:179-191);
+//   select   the greedy left-to-right parse "next = first match at or after the end of the current one" is the orbit
+//            of a jump function over the tile; it is computed by pointer doubling with all 1024 lanes (log2 rounds,
+//            early exit through __syncthreads_or) instead of a serial walk;
+//   finish   matches that hit the 32-byte cap are completed by wave 0 with 64 lanes x 8 bytes per step, in order,
+//            dropping the selections they swallow;
+//   emit     every selected match computes its own sequence in parallel (rank by popcount prefix, literal length from
+//            the previous selected match's end, backward extension as ZstdFast.cs:242-247);
+//   literals bytes not covered by a selected match are compacted 16 per lane.
 //
-// LDS (one workgroup per CU): chunk bytes 64 KiB (+pad) | 2 hash tables u32[8192] 64 KiB | tile arrays 3 KiB |
-// coverage bitmask 8 KiB.  HBM traffic per chunk: read n, write literals (<= n) + 8 B per sequence.
+// Offsets are stored raw (distance + 3); the repcode assignment, which is a serial state machine over the sequences
+// (U/ZstdDecompressBlock.cs:2387-2443), runs in seq_encode's per-chunk serial section.  All table updates are
+// commutative atomics and every parallel step is order-independent, so the output is deterministic.
+//
+// LDS (one workgroup per CU, ~152 KiB): chunk 64 KiB (+pad) | 2 hash tables u32[8192] | tile arrays.
+// HBM traffic per chunk: read n, write literals (<= n) + 8 B per sequence.
 #include "zmi_device.h"
 
 namespace zmi {
 
 constexpr u32 kHashLog  = 13;            // the reference's hashLog for level 1 at <= 128 KiB (U/Clevels.cs:488)
 constexpr u32 kTile     = 1024;          // threads per workgroup
-constexpr u32 kPPT      = 4;             // positions per thread per tile (independent probes in flight per lane)
-constexpr u32 kTilePos  = kTile * kPPT;  // positions per tile
-constexpr u32 kTileLog  = 12;            // log2(kTilePos)
-static_assert((1u << kTileLog) == kTilePos, "tile geometry");
-constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; the selecting wave extends the rest
+constexpr u32 kPPT      = 4;             // positions per thread per tile
+constexpr u32 kTilePos  = kTile * kPPT;  // 4096 positions per tile
+constexpr u32 kTileLog  = 12;
+constexpr u32 kGroups   = kTilePos / 64; // 64-position groups per tile
+constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; capped matches are finished by wave 0
 constexpr u32 kInPad    = 64;
+constexpr u32 kExit     = 0xFFFFu;       // jump target "leaves the tile"
+static_assert((1u << kTileLog) == kTilePos && kGroups == 64, "tile geometry");
 
 struct LzLds {
     u8  in[kChunkSize + kInPad];
     u32 table[1u << kHashLog];           // position+1 of the latest occurrence of the hash in EARLIER tiles; 0 = empty
     u32 first[1u << kHashLog];           // first occurrence of the hash inside the CURRENT tile: ((15-tile) << 12) | index
+    u8  tileLen[kTilePos];               // match length at each position of the tile (0 = none, kLenCap = "at least")
     u16 tileOff[kTilePos];
-    u8  tileLen[kTilePos];
-    u32 cov[kChunkSize / 32];            // bit p set <=> byte p is covered by a selected match
-    u64 tileMask[kTilePos / 64];         // per 64-position group of the current tile: lanes that hold a match
+    u16 jump[kTilePos];                  // pointer-doubling array; afterwards: full length of capped selected matches
+    u64 matchMask[kGroups];              // bit = position holds a match
+    u64 capMask[kGroups];                // bit = that match hit the cap
+    u64 selMask[kGroups];                // bit = match is on the greedy orbit (selected)
+    u64 covMask[kGroups];                // bit = byte covered by a selected match (tile-local)
+    u32 wordRank[kGroups + 1];           // selected matches before each group
+    u32 endOf[kTilePos / 4 + 2];         // endOf[r+1] = absolute end of the r-th selected match of the tile; endOf[0] = anchor
     u32 waveCnt[2][16];
-    u32 nbSeq, anchorEnd;
+    u64 nzWords;                         // bit g = matchMask[g] != 0
+    u32 cursor, anchor, nbSeq, litBase;
 };
 
 __device__ __forceinline__ u32 hash6(u64 w) { return (u32)(((w << 16) * 227718039650203ULL) >> (64 - kHashLog)); }
+__device__ __forceinline__ u64 read_lane64(u64 v, u32 l) { return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32); }
 
-struct Walk { u32 cur, anchor, nbSeq, rep0, rep1, rep2; };
-
-// Greedy selection over one tile, executed by wave 0 with all 64 lanes (control flow is wave-uniform).
-__device__ __forceinline__ void walk_tile(LzLds& L, u32 n, u32 tileStart, Seq* __restrict__ seqOut, Walk& st)
+// length of the match between position p (its first 8 bytes are w) and cpos < p, capped; 0 if shorter than 4
+__device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w, u32 n)
 {
-    const u32 lane = lane_id();
-    // groups of this tile that hold at least one match: the walker only visits those
-    u64 groups = ballot(lane < kTilePos / 64 && L.tileMask[lane % (kTilePos / 64)] != 0);
-    while (groups) {
-        const u32 g = ctz64(groups);
-        groups &= groups - 1;
-        const u32 gbase = tileStart + g * 64;
-        if (st.cur >= gbase + 64) continue;
-        const u32 myLen = L.tileLen[g * 64 + lane];
-        const u32 myOff = L.tileOff[g * 64 + lane];
-        u64 mask = ballot(myLen != 0);
-        if (st.cur > gbase) mask &= ~0ull << (st.cur - gbase);
-        while (mask) {
-            const u32 f = ctz64(mask);
-            u32 pos = gbase + f;
-            u32 len = read_lane(myLen, f);
-            const u32 off = read_lane(myOff, f);
-            // forward: a capped lane length means "at least kLenCap": finish it with 64 lanes x 8 bytes per step
-            if (len == kLenCap) {
-                u32 e = pos + len;
-                for (;;) {
-                    const u32 q = e + 8 * lane;                       // reads past n land in the table region: harmless, clamped below
-                    const u64 x = readLE64(L.in + q) ^ readLE64(L.in + q - off);
-                    const u64 bad = ballot(x != 0 || q + 8 > n);
-                    if (bad == 0) { e += 512; continue; }
-                    const u32 fl = ctz64(bad);
-                    const u32 cnt = x ? (ctz64(x) >> 3) : 8;
-                    e += 8 * fl + read_lane(cnt, fl);
-                    break;
-                }
-                if (e > n) e = n;
-                len = e - pos;
-            }
-            // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
-            for (;;) {
-                u32 maxBack = pos - st.anchor;
-                const u32 cpos = pos - off;
-                if (cpos < maxBack) maxBack = cpos;
-                if (maxBack > 64) maxBack = 64;
-                const bool eq = lane < maxBack && L.in[pos - 1 - lane] == L.in[cpos - 1 - lane];
-                const u64 b = ballot(eq);
-                const u32 back = (~b == 0) ? 64 : ctz64(~b);
-                pos -= back; len += back;
-                if (back < 64) break;
-            }
-            if (st.nbSeq < kMaxSeq) {
-                const u32 litLen = pos - st.anchor;
-                const u32 ll0 = litLen == 0;
-                u32 code;
-                if (!ll0) code = off == st.rep0 ? 1 : off == st.rep1 ? 2 : off == st.rep2 ? 3 : off + 3;
-                else      code = off == st.rep1 ? 1 : off == st.rep2 ? 2 : (off == st.rep0 - 1 && st.rep0 > 1) ? 3 : off + 3;
-                if (code > 3) { st.rep2 = st.rep1; st.rep1 = st.rep0; st.rep0 = off; }
-                else {
-                    const u32 idx = code - 1 + ll0;
-                    if (idx == 1) { const u32 t = st.rep1; st.rep1 = st.rep0; st.rep0 = t; }
-                    else if (idx == 2) { const u32 t = st.rep2; st.rep2 = st.rep1; st.rep1 = st.rep0; st.rep0 = t; }
-                    else if (idx == 3) { const u32 t = st.rep0 - 1; st.rep2 = st.rep1; st.rep1 = st.rep0; st.rep0 = t; }
-                }
-                if (lane == 0) { Seq s; s.offBase = code; s.litLength = (u16)litLen; s.mlBase = (u16)(len - 3); seqOut[st.nbSeq] = s; }
-                st.nbSeq++;
-                // mark [pos, pos+len) covered
-                {
-                    const u32 last = pos + len - 1, w0 = pos >> 5, w1 = last >> 5;
-                    for (u32 w = w0 + lane; w <= w1; w += 64) {
-                        u32 m = ~0u;
-                        if (w == w0) m &= ~0u << (pos & 31);
-                        if (w == w1) m &= ~0u >> (31 - (last & 31));
-                        L.cov[w] |= m;
-                    }
-                }
-                st.anchor = st.cur = pos + len;
-            } else {
-                st.cur = pos + 1;          // sequence budget exhausted: the rest of the chunk stays literal
-                mask = 0;
-                break;
-            }
-            mask = (st.cur - gbase < 64) ? (mask & (~0ull << (st.cur - gbase))) : 0;
+    u64 x = w ^ readLE64(L.in + cpos);
+    if ((u32)x != 0) return 0;
+    u32 l = x ? (ctz64(x) >> 3) : 8;
+    if (!x) {
+        while (l < kLenCap) {
+            x = readLE64(L.in + p + l) ^ readLE64(L.in + cpos + l);
+            if (x) { l += ctz64(x) >> 3; break; }
+            l += 8;
         }
     }
+    if (l > n - p) l = n - p;
+    if (l > kLenCap) l = kLenCap;
+    return l >= 4 ? l : 0;
+}
+
+// first match position >= c inside the tile (tile-relative), or kExit
+__device__ __forceinline__ u32 next_match(const LzLds& L, u32 c)
+{
+    if (c >= kTilePos) return kExit;
+    const u32 wi = c >> 6;
+    const u64 w = L.matchMask[wi] >> (c & 63);
+    if (w) return c + ctz64(w);
+    const u64 rest = wi + 1 < kGroups ? (L.nzWords >> (wi + 1)) : 0;
+    if (!rest) return kExit;
+    const u32 wj = wi + 1 + ctz64(rest);
+    return wj * 64 + ctz64(L.matchMask[wj]);
 }
 
 __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ src, u64 srcSize,
@@ -152,95 +113,236 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     for (u32 i = tid; i < (1u << kHashLog); i += kTile) { L.table[i] = 0; L.first[i] = 0xFFFFFFFFu; }
-    for (u32 i = tid; i < kChunkSize / 32; i += kTile) L.cov[i] = 0;
+    if (tid == 0) { L.cursor = 0; L.anchor = 0; L.nbSeq = 0; L.litBase = 0; }
     __syncthreads();
 
-    Walk st; st.cur = 0; st.anchor = 0; st.nbSeq = 0; st.rep0 = 1; st.rep1 = 4; st.rep2 = 8;
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
+    u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
 
     // Matches may start where 8 bytes are still readable (the reference stops at iend-8, ZstdFast.cs:110).
     const u32 nTiles = (n + kTilePos - 1) / kTilePos;
     for (u32 t = 0; t < nTiles; ++t) {
+        const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
+        // ---------------- probe ----------------
         u64 w[kPPT]; u32 h[kPPT], cand[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = t * kTilePos + q;
+            const u32 q = j * kTile + tid, p = tileStart + q;
             valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cand[j] = 0;
             if (valid[j]) { w[j] = readLE64(L.in + p); h[j] = hash6(w[j]); cand[j] = L.table[h[j]]; atomicMin(&L.first[h[j]], stamp | q); }
         }
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = t * kTilePos + q;
+            const u32 q = j * kTile + tid, p = tileStart + q;
+            u32 len = 0, off = 0;
             if (valid[j]) {
                 atomicMax(&L.table[h[j]], p + 1);
-                const u32 f = L.first[h[j]];   // same-tile first occurrence: nearer than anything in the cross-tile table
-                if ((f >> kTileLog) == (stamp >> kTileLog) && (f & (kTilePos - 1)) < q) cand[j] = t * kTilePos + (f & (kTilePos - 1)) + 1;
-            }
-        }
+                // (1) periods 1..4: bytes p..p+7 repeat with period d and the d bytes before p agree — runs and tiny
+                //     patterns, which neither table can see inside one tile
+                u32 per = 0;
+                if (p >= 4) {
+                    const u32 prev4 = readLE32(L.in + p - 4);
 #pragma unroll
-        for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = t * kTilePos + q;
-            u32 len = 0, off = 0;
-            if (cand[j]) {
-                const u32 cpos = cand[j] - 1;
-                u64 x = w[j] ^ readLE64(L.in + cpos);
-                if ((u32)x == 0) {             // >= 4 equal bytes, as the reference's MEM_read32 check (ZstdFast.cs:179-191)
-                    u32 l = x ? (ctz64(x) >> 3) : 8;
-                    if (!x) {
-                        while (l < kLenCap) {
-                            x = readLE64(L.in + p + l) ^ readLE64(L.in + cpos + l);
-                            if (x) { l += ctz64(x) >> 3; break; }
-                            l += 8;
-                        }
+                    for (u32 d = 4; d >= 1; --d) {
+                        const u64 m = (1ull << (64 - 8 * d)) - 1;
+                        const bool inner = ((w[j] >> (8 * d)) & m) == (w[j] & m);
+                        const bool lead = (prev4 >> (8 * (4 - d))) == (u32)(w[j] & ((1ull << (8 * d)) - 1));
+                        if (inner && lead) per = d;
                     }
-                    if (l > n - p) l = n - p;
-                    if (l > kLenCap) l = kLenCap;
-                    if (l >= 4) { len = l; off = p - cpos; }
+                }
+                if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
+                else {
+                    // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
+                    const u32 f = L.first[h[j]];
+                    if ((f >> kTileLog) == (stamp >> kTileLog) && (f & (kTilePos - 1)) < q) {
+                        const u32 cpos = tileStart + (f & (kTilePos - 1));
+                        len = match_len(L, p, cpos, w[j], n); off = p - cpos;
+                    }
+                    if (cand[j] && len < kLenCap) {
+                        const u32 cpos = cand[j] - 1;
+                        const u32 l2 = match_len(L, p, cpos, w[j], n);
+                        if (l2 > len) { len = l2; off = p - cpos; }
+                    }
                 }
             }
             L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off;
-            { const u64 mm = ballot(len != 0); if (lane == 0) L.tileMask[j * (kTile / 64) + wave] = mm; }
+            const u64 mm = ballot(len != 0), cm = ballot(len == kLenCap);
+            if (lane == 0) { L.matchMask[j * 16 + wave] = mm; L.capMask[j * 16 + wave] = cm; L.selMask[j * 16 + wave] = 0; }
         }
-        __syncthreads();                       // tile arrays and inserts visible
-        if (wave == 0) walk_tile(L, n, t * kTilePos, seqOut, st);
-        // the other 15 waves run ahead into the next tile's probes; they meet wave 0 at that tile's first barrier
-    }
-    if (tid == 0) { L.nbSeq = st.nbSeq; }
-    __syncthreads();
-
-    // ---- literals: every byte not covered by a selected match, in order; 16 positions per thread per round ----
-    u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
-    u32 litBase = 0;
-    const u32 nRounds = (n + 16 * kTile - 1) / (16 * kTile);
-    for (u32 r = 0; r < nRounds; ++r) {
-        const u32 p = (r * kTile + tid) * 16;
-        u32 keep = 0;                                         // bit k set <=> byte p+k is a literal
-        if (p < n) {
-            const u32 covw = L.cov[p >> 5] >> (p & 31);       // p is a multiple of 16: the 16 bits sit in one word
-            keep = ~covw & 0xFFFFu;
-            if (n - p < 16) keep &= (1u << (n - p)) - 1;
-        }
-        const u32 cnt = __builtin_popcount(keep);
-        const u32 incl = wave_scan_incl(cnt);
-        if (lane == 63) L.waveCnt[r & 1][wave] = incl;
         __syncthreads();
-        u32 before = 0, total = 0;
-#pragma unroll
-        for (u32 k = 0; k < 16; ++k) { const u32 v = L.waveCnt[r & 1][k]; total += v; if (k < wave) before += v; }
-        u8* o = litOut + litBase + before + incl - cnt;
-        if (keep == 0xFFFFu) {
-            const uint4 v = *reinterpret_cast<const uint4*>(L.in + p);
-            *(u32u*)(o) = v.x; *(u32u*)(o + 4) = v.y; *(u32u*)(o + 8) = v.z; *(u32u*)(o + 12) = v.w;
-        } else {
-            while (keep) { const u32 k = __builtin_ctz(keep); keep &= keep - 1; *o++ = L.in[p + k]; }
+        // ---------------- select: orbit of the greedy parse by pointer doubling ----------------
+        if (wave == 0) {
+            const u64 nz = ballot(L.matchMask[lane] != 0);
+            if (lane == 0) L.nzWords = nz;
         }
-        litBase += total;
+        __syncthreads();
+        const u32 cursor = L.cursor;            // absolute position where the previous tiles' parse ended
+        const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;
+        if (L.nzWords != 0 && c0 < kTilePos) {  // (uniform) something to select in this tile
+#pragma unroll
+            for (u32 j = 0; j < kPPT; ++j) {
+                const u32 q = j * kTile + tid;
+                const u32 len = L.tileLen[q];
+                if (len) L.jump[q] = (u16)next_match(L, q + len);
+            }
+            if (tid == 0) { const u32 s0 = next_match(L, c0); if (s0 != kExit) L.selMask[s0 >> 6] = 1ull << (s0 & 63); }
+            __syncthreads();
+            for (u32 round = 0; round < kTileLog; ++round) {
+                u32 nv[kPPT]; u32 added = 0;
+#pragma unroll
+                for (u32 j = 0; j < kPPT; ++j) {
+                    const u32 q = j * kTile + tid;
+                    nv[j] = kExit;
+                    if (L.tileLen[q]) {
+                        const u32 jq = L.jump[q];
+                        if (jq != kExit) {
+                            if ((L.selMask[q >> 6] >> (q & 63)) & 1ull) {
+                                const u64 bit = 1ull << (jq & 63);
+                                const u64 old = atomicOr((unsigned long long*)&L.selMask[jq >> 6], (unsigned long long)bit);
+                                added |= !(old & bit);
+                            }
+                            nv[j] = L.jump[jq];
+                        }
+                    }
+                }
+                const int any = __syncthreads_or((int)added);     // all reads of jump[] done; did the orbit grow?
+#pragma unroll
+                for (u32 j = 0; j < kPPT; ++j) { const u32 q = j * kTile + tid; if (L.tileLen[q]) L.jump[q] = (u16)nv[j]; }
+                __syncthreads();
+                if (!any) break;
+            }
+            // ---------------- finish capped matches in order; drop the selections they swallow (wave 0) ----------------
+            if (wave == 0) {
+                u32 from = 0;                  // consider selected capped matches at tile positions >= from
+                while (from < kTilePos) {
+                    u64 wm = L.selMask[lane] & L.capMask[lane];       // lane = group index; re-read every time
+                    if (lane < (from >> 6)) wm = 0; else if (lane == (from >> 6)) wm &= ~0ull << (from & 63);
+                    const u64 have = ballot(wm != 0);
+                    if (!have) break;
+                    const u32 g = ctz64(have);
+                    const u32 q = g * 64 + ctz64(read_lane64(wm, g));
+                    const u32 p = tileStart + q, off = L.tileOff[q];
+                    u32 e = p + kLenCap;
+                    for (;;) {
+                        const u32 pos = e + 8 * lane;              // reads past n land in the table region: harmless, clamped below
+                        const u64 x = readLE64(L.in + pos) ^ readLE64(L.in + pos - off);
+                        const u64 bad = ballot(x != 0 || pos + 8 > n);
+                        if (bad == 0) { e += 512; continue; }
+                        const u32 fl = ctz64(bad);
+                        const u32 cnt = x ? (ctz64(x) >> 3) : 8;
+                        e += 8 * fl + read_lane(cnt, fl);
+                        break;
+                    }
+                    if (e > n) e = n;
+                    if (lane == 0) L.jump[q] = (u16)(e - p > 0xFFFFu ? 0xFFFFu : e - p);
+                    const u32 r0 = q + 1, r1 = (e - tileStart) < kTilePos ? (e - tileStart) : kTilePos;   // swallowed: [r0, r1)
+                    if (r1 > r0) {
+                        const u32 w0 = r0 >> 6, w1 = (r1 - 1) >> 6;
+                        if (lane >= w0 && lane <= w1) {
+                            u64 m = ~0ull;
+                            if (lane == w0) m &= ~0ull << (r0 & 63);
+                            if (lane == w1) m &= ~0ull >> (63 - ((r1 - 1) & 63));
+                            L.selMask[lane] &= ~m;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    }
+                    from = r1 > r0 ? r1 : r0;
+                }
+            }
+            __syncthreads();
+        }
+        // ---------------- emit ----------------
+        if (wave == 0) {        // ranks: selected matches before each group
+            const u32 cnt = popc64(L.selMask[lane]);
+            const u32 incl = wave_scan_incl(cnt);
+            L.wordRank[lane] = incl - cnt;
+            if (lane == 63) L.wordRank[64] = incl;
+            if (lane == 0) L.endOf[0] = L.anchor;
+            L.covMask[lane] = 0;
+        }
+        __syncthreads();
+        const u32 nSel = L.wordRank[64];
+        const u32 nbSeqBase = L.nbSeq;
+        u32 myRank[kPPT], myEnd[kPPT]; bool sel[kPPT];
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 q = j * kTile + tid;
+            const u64 sm = L.selMask[q >> 6];
+            sel[j] = (sm >> (q & 63)) & 1ull;
+            myRank[j] = 0; myEnd[j] = 0;
+            if (sel[j]) {
+                myRank[j] = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
+                const u32 len = L.tileLen[q];
+                myEnd[j] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
+                L.endOf[myRank[j] + 1] = myEnd[j];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            if (!sel[j]) continue;
+            const u32 q = j * kTile + tid;
+            u32 p = tileStart + q;
+            const u32 off = L.tileOff[q];
+            const u32 litStart = L.endOf[myRank[j]];
+            const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
+            // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
+            while (p > floorPos && p > off && L.in[p - 1] == L.in[p - off - 1]) --p;
+            Seq s; s.offBase = off + 3; s.litLength = (u16)(p - litStart); s.mlBase = (u16)(myEnd[j] - p - 3);
+            seqOut[nbSeqBase + myRank[j]] = s;
+            // coverage inside this tile
+            const u32 r0 = p - tileStart, r1 = (myEnd[j] - tileStart) < kTilePos ? (myEnd[j] - tileStart) : kTilePos;
+            for (u32 wI = r0 >> 6; wI <= ((r1 - 1) >> 6); ++wI) {
+                u64 m = ~0ull;
+                if (wI == (r0 >> 6)) m &= ~0ull << (r0 & 63);
+                if (wI == ((r1 - 1) >> 6)) m &= ~0ull >> (63 - ((r1 - 1) & 63));
+                atomicOr((unsigned long long*)&L.covMask[wI], (unsigned long long)m);
+            }
+        }
+        __syncthreads();
+        // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
+        {
+            const u32 q16 = tid * 16;              // 256 threads cover the tile, 16 positions each
+            u32 keep = 0;
+            if (tid < kTilePos / 16) {
+                const u32 p = tileStart + q16;
+                if (p < n) {
+                    const u32 covw = (u32)(L.covMask[q16 >> 6] >> (q16 & 63));
+                    keep = ~covw & 0xFFFFu;
+                    if (n - p < 16) keep &= (1u << (n - p)) - 1;
+                    if (c0 > q16) keep &= (c0 - q16 >= 16) ? 0u : (0xFFFFu << (c0 - q16));     // before the entry cursor: inside an earlier match
+                }
+            }
+            const u32 cnt = __builtin_popcount(keep);
+            const u32 incl = wave_scan_incl(cnt);
+            if (lane == 63) L.waveCnt[t & 1][wave] = incl;
+            __syncthreads();
+            u32 before = 0, total = 0;
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) { const u32 v = L.waveCnt[t & 1][k]; total += v; if (k < wave) before += v; }
+            if (tid < kTilePos / 16 && keep) {
+                const u32 p = tileStart + q16;
+                u8* o = litOut + L.litBase + before + incl - cnt;
+                if (keep == 0xFFFFu) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(L.in + p);
+                    *(u32u*)(o) = v.x; *(u32u*)(o + 4) = v.y; *(u32u*)(o + 8) = v.z; *(u32u*)(o + 12) = v.w;
+                } else {
+                    while (keep) { const u32 k = __builtin_ctz(keep); keep &= keep - 1; *o++ = L.in[p + k]; }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                L.litBase += total;
+                if (nSel) { const u32 e = L.endOf[nSel]; L.anchor = e; L.cursor = e; L.nbSeq = nbSeqBase + nSel; }
+            }
+            __syncthreads();
+        }
     }
     if (tid == 0) {
         ChunkMeta m = {};
-        m.srcSize = n; m.nbSeq = L.nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(n);
+        m.srcSize = n; m.nbSeq = L.nbSeq; m.litSize = L.litBase; m.fhSize = frame_header_size(n);
         meta[c] = m;
     }
 }
@@ -251,7 +353,7 @@ void launch_lz_fast(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits
 {
     static bool attrSet = false;
     if (!attrSet) {
-        hipFuncSetAttribute(reinterpret_cast<const void*>(lz_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet = true;
     }
     hipLaunchKernelGGL(lz_fast_kernel, dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta);

@@ -86,8 +86,8 @@ __device__ inline u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count, u32 max
     }
 }
 
-__global__ __launch_bounds__(256) void seq_encode_kernel(const Seq* __restrict__ seqs, ChunkMeta* __restrict__ meta,
-                                                         u8* __restrict__ slots, u32 nChunks, u32 strategy, u32 checksumFlag)
+__global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs, ChunkMeta* __restrict__ meta,
+                                                         u8* __restrict__ slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps)
 {
     __shared__ SeqWaveLds Ws[4];
     const u32 lane = lane_id(), wave = wave_id();
@@ -96,12 +96,41 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(const Seq* __restrict__
     SeqWaveLds& W = Ws[wave];
     ChunkMeta m = meta[c];
     const u32 nbSeq = m.nbSeq, n = m.srcSize;
-    const Seq* __restrict__ sq = seqs + (u64)c * kMaxSeq;
+    Seq* __restrict__ sq = seqs + (u64)c * kMaxSeq;
     u8* const slot = slots + (u64)c * kSlotStride;
     u8* const body = slot + m.fhSize + 3;
 
     for (u32 i = lane; i < 3 * 64; i += 64) (&W.count[0][0])[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    if (resolveReps) {
+        // The match finder stores raw offsets (distance + 3).  Turning them into repcodes is a serial state machine over
+        // the sequences — the decoder's history rule (U/ZstdDecompressBlock.cs:2387-2443) run forward — so it lives
+        // here: 64 sequences are loaded per step (coalesced), the chain itself runs on scalar values.
+        u32 rep0 = 1, rep1 = 4, rep2 = 8;
+        for (u32 b0 = 0; b0 < nbSeq; b0 += 64) {
+            const u32 i = b0 + lane;
+            Seq s; s.offBase = 4; s.litLength = 0; s.mlBase = 0;
+            if (i < nbSeq) s = sq[i];
+            const u32 myOff = s.offBase - 3, myLL = s.litLength;
+            u32 myCode = s.offBase;
+            const u32 cnt = nbSeq - b0 < 64 ? nbSeq - b0 : 64;
+            for (u32 k = 0; k < cnt; k++) {
+                const u32 off = read_lane(myOff, k), ll0 = read_lane(myLL, k) == 0;
+                u32 code;
+                if (!ll0) code = off == rep0 ? 1 : off == rep1 ? 2 : off == rep2 ? 3 : off + 3;
+                else      code = off == rep1 ? 1 : off == rep2 ? 2 : (off == rep0 - 1 && rep0 > 1) ? 3 : off + 3;
+                if (code > 3) { rep2 = rep1; rep1 = rep0; rep0 = off; }
+                else {
+                    const u32 idx = code - 1 + ll0;
+                    if (idx == 1) { const u32 tt = rep1; rep1 = rep0; rep0 = tt; }
+                    else if (idx == 2) { const u32 tt = rep2; rep2 = rep1; rep1 = rep0; rep0 = tt; }
+                    else if (idx == 3) { const u32 tt = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = tt; }
+                }
+                if (lane == k) myCode = code;
+            }
+            if (i < nbSeq) sq[i].offBase = myCode;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
     for (u32 i = lane; i < nbSeq; i += 64) {
         const Seq s = sq[i];
@@ -180,9 +209,9 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(const Seq* __restrict__
     meta[c] = m;
 }
 
-void launch_seq_encode(const Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, hipStream_t stream)
+void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag);
+    hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag, resolveReps);
 }
 
 } // namespace zmi
