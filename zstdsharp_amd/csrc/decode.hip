@@ -160,6 +160,7 @@ struct SeqLds {
     u16 symbolNext[64];
     u32 llLog, mlLog, ofLog;
     u32 llValid, mlValid, ofValid;
+    u32 bLL[64], bML[64], bOFF[64];     // one batch of decoded sequences (lane 0 decodes, 64 lanes execute)
 };
 
 __constant__ u8  dLL_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
@@ -759,6 +760,46 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 la
     for (u32 i = lane; i < n; i += 64) d[i] = s0[i % offset];
 }
 
+// Backward bit reader for the sequence section, used by ONE lane (U/Bitstream.cs:172-426).  Same container scheme as
+// the literal streams: `cont` holds 64 stream bits, re-based by whole bytes from `raw`, the 8 bytes below it, which
+// are fetched one re-base ahead.  Bytes outside the stream read as zero (the reference's overflow behaviour).
+struct SeqBits {
+    const u8* s; s32 size, ptr, lp; u64 cont, raw; u32 consumed;
+    __device__ __forceinline__ u64 load8z(s32 idx) const
+    {
+        if (idx >= 0 && idx + 8 <= size) return readLE64(s + idx);
+        u64 v = 0;
+        for (s32 i = 0; i < 8; i++) { const s32 k = idx + i; if (k >= 0 && k < size) v |= (u64)s[k] << (8 * i); }
+        return v;
+    }
+    __device__ __forceinline__ bool init(const u8* p, s32 n)
+    {
+        s = p; size = n; ptr = 0; lp = 0; cont = 0; raw = 0; consumed = 0;
+        if (n < 1) return false;
+        const u32 last = p[n - 1];
+        if (!last) return false;
+        const s32 remaining = (n - 1) * 8 + (s32)highbit32(last);
+        ptr = n - 8; cont = load8z(ptr); lp = ptr - 8; raw = load8z(lp);
+        consumed = 64u - (u32)(remaining - 8 * ptr);
+        return true;
+    }
+    __device__ __forceinline__ void rebase()           // afterwards consumed <= 7: up to 57 bits can be read
+    {
+        const u32 k = consumed >> 3;
+        if (k) {
+            cont = k >= 8 ? raw : ((cont << (8 * k)) | (raw >> (64 - 8 * k)));
+            ptr -= (s32)k; consumed -= 8 * k; lp = ptr - 8; raw = load8z(lp);
+        }
+    }
+    __device__ __forceinline__ u32 read(u32 nb) { const u32 v = nb ? (u32)((cont << consumed) >> (64 - nb)) : 0u; consumed += nb; return v; }
+    __device__ __forceinline__ s32 remaining() const { return 8 * ptr + 64 - (s32)consumed; }
+};
+
+// Sequences of one frame on one wave.  Per block: lane 0 runs the serial state chain (ZSTD_decodeSequence,
+// U/ZstdDecompressBlock.cs:2360-2484) 64 sequences at a time into LDS; then all 64 lanes execute the batch
+// (ZSTD_execSequence, :2187-2262): output positions by prefix sum, every lane copies its own sequence's literals and
+// its own match when the match source lies entirely in output produced before this batch; the remaining matches
+// (near, overlapping or long) run in sequence order, 64 lanes per match.
 __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out,
                                       const u8* __restrict__ litIn, const u32 lane)
 {
@@ -766,7 +807,6 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
     u32 ip = h.headerSize, op = 0, litOff = 0;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;
-    u32 fenced = 0;                       // output bytes [0, fenced) are known visible to every lane of this wave
     if (lane == 0) { L.llValid = L.mlValid = L.ofValid = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     for (;;) {
@@ -800,10 +840,6 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                 lit = litIn + litOff; litOff += litSize; bp = lh.lhSize + lh.litCSize;
             } else if (lh.type == 0) { lit = b + lh.lhSize; bp = lh.lhSize + litSize; }
             else { litIsRle = true; rleByte = b[lh.lhSize]; bp = lh.lhSize + 1; }
-            auto copy_literals = [&](u32 dstOff, u32 litPos, u32 n) {
-                if (litIsRle) { for (u32 i = lane; i < n; i += 64) out[dstOff + i] = (u8)rleByte; }
-                else wave_copy(out + dstOff, lit + litPos, n, lane);
-            };
             // ---- sequences header (ZSTD_decodeSeqHeaders, :1845-1943) ----
             if (bp >= bend) FAIL(kErrSrcSizeWrong);
             u32 nbSeq = b[bp++];
@@ -830,68 +866,102 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                 bp += adv;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
             }
-            // ---- sequences (ZSTD_decompressSequences_body, :2668-2763) ----
+            // ---- sequences (ZSTD_decompressSequences_body, :2668-2763), 64 at a time ----
             u32 litPos = 0;
             if (nbSeq) {
-                BackBits bd; bd.base = nullptr; bd.size = 0; bd.pos = 0; bd.win = 0; bd.wStart = 0;
-                u32 okInit = 1, sLL = 0, sOF = 0, sML = 0;
+                SeqBits bd; u32 okInit = 1, sLL = 0, sOF = 0, sML = 0;
+                bd.s = nullptr; bd.size = 0; bd.ptr = 0; bd.lp = 0; bd.cont = 0; bd.raw = 0; bd.consumed = 0;
                 if (lane == 0) {
                     okInit = bd.init(b + bp, (s32)(bend - bp)) ? 1u : 0u;
-                    if (okInit) { sLL = bd.read(L.llLog); sOF = bd.read(L.ofLog); sML = bd.read(L.mlLog); }
+                    if (okInit) { bd.rebase(); sLL = bd.read(L.llLog); sOF = bd.read(L.ofLog); sML = bd.read(L.mlLog); }
                 }
                 if (!uniform(okInit)) FAIL(kErrCorruption);
-                for (u32 n = 0; n < nbSeq; n++) {
-                    u32 litLength = 0, matchLength = 0, offset = 0;
-                    if (lane == 0) {     // ZSTD_decodeSequence (:2360-2484)
-                        const SeqSym ll = L.ll[sLL], ml = L.ml[sML], of = L.of[sOF];
-                        matchLength = ml.baseValue; litLength = ll.baseValue;
-                        if (of.nbAddBits > 1) {
-                            offset = of.baseValue + bd.read(of.nbAddBits);
-                            rep2 = rep1; rep1 = rep0; rep0 = offset;
-                        } else {
-                            const u32 ll0 = ll.baseValue == 0;
-                            if (of.nbAddBits == 0) {
-                                offset = ll0 ? rep1 : rep0;
-                                rep1 = ll0 ? rep0 : rep1;
-                                rep0 = offset;
+                for (u32 base = 0; base < nbSeq; base += 64) {
+                    const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
+                    if (lane == 0) {
+                        for (u32 k = 0; k < cnt; k++) {     // ZSTD_decodeSequence (:2360-2484)
+                            const SeqSym ll = L.ll[sLL], ml = L.ml[sML], of = L.of[sOF];
+                            u32 matchLength = ml.baseValue, litLength = ll.baseValue, offset;
+                            bd.rebase();
+                            if (of.nbAddBits > 1) {
+                                offset = of.baseValue + bd.read(of.nbAddBits);
+                                rep2 = rep1; rep1 = rep0; rep0 = offset;
+                                if (of.nbAddBits > 24) bd.rebase();
                             } else {
-                                const u32 code = of.baseValue + ll0 + bd.read(1);
-                                u32 temp = code == 3 ? rep0 - 1 : (code == 1 ? rep1 : code == 2 ? rep2 : rep0);
-                                temp += !temp;
-                                if (code != 1) rep2 = rep1;
-                                rep1 = rep0; rep0 = temp; offset = temp;
+                                const u32 ll0 = ll.baseValue == 0;
+                                if (of.nbAddBits == 0) {
+                                    offset = ll0 ? rep1 : rep0;
+                                    rep1 = ll0 ? rep0 : rep1;
+                                    rep0 = offset;
+                                } else {
+                                    const u32 code = of.baseValue + ll0 + bd.read(1);
+                                    u32 temp = code == 3 ? rep0 - 1 : (code == 1 ? rep1 : code == 2 ? rep2 : rep0);
+                                    temp += !temp;
+                                    if (code != 1) rep2 = rep1;
+                                    rep1 = rep0; rep0 = temp; offset = temp;
+                                }
                             }
+                            if (ml.nbAddBits) matchLength += bd.read(ml.nbAddBits);
+                            if (ll.nbAddBits) litLength += bd.read(ll.nbAddBits);
+                            bd.rebase();
+                            sLL = ll.nextState + bd.read(ll.nbBits);
+                            sML = ml.nextState + bd.read(ml.nbBits);
+                            sOF = of.nextState + bd.read(of.nbBits);
+                            L.bLL[k] = litLength; L.bML[k] = matchLength; L.bOFF[k] = offset;
                         }
-                        if (ml.nbAddBits) matchLength += bd.read(ml.nbAddBits);
-                        if (ll.nbAddBits) litLength += bd.read(ll.nbAddBits);
-                        sLL = ll.nextState + bd.read(ll.nbBits);
-                        sML = ml.nextState + bd.read(ml.nbBits);
-                        sOF = of.nextState + bd.read(of.nbBits);
                     }
-                    litLength = uniform(litLength); matchLength = uniform(matchLength); offset = uniform(offset);
-                    // ZSTD_execSequence (:2187-2262)
-                    if (litLength > litSize - litPos) FAIL(kErrCorruption);
-                    if ((u64)litLength + matchLength > fd.dstSize - op) FAIL(kErrCorruption);
-                    copy_literals(op, litPos, litLength);
-                    op += litLength; litPos += litLength;
-                    if (offset > op || offset == 0) FAIL(kErrCorruption);
-                    // the match reads [op-offset, op-offset+min(offset, matchLength)): stores of this wave that are not
-                    // yet known visible to its other lanes need one fence first
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    // ---- execute the batch (ZSTD_execSequence, :2187-2262) ----
+                    const bool have = lane < cnt;
+                    const u32 ll = have ? L.bLL[lane] : 0, ml = have ? L.bML[lane] : 0, off = have ? L.bOFF[lane] : 1;
+                    const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
+                    const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
+                    if (totalLit > litSize - litPos) FAIL(kErrCorruption);
+                    if (totalOut > fd.dstSize - op) FAIL(kErrCorruption);
+                    const u32 dLit = op + inclOut - ll - ml;            // where my literals go
+                    const u32 dMatch = dLit + ll;                       // where my match goes
+                    const u32 sLit = litPos + inclLit - ll;
+                    if (ballot(have && (off > dMatch || off == 0))) FAIL(kErrCorruption);
+                    // literals: short runs by their own lane, long runs by the whole wave
                     {
-                        const u32 srcEnd = op - offset + (offset < matchLength ? offset : matchLength);
-                        if (srcEnd > fenced) { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); fenced = op; }
+                        const bool longLit = ll > 32;
+                        if (have && !longLit) {
+                            if (litIsRle) for (u32 i = 0; i < ll; i++) out[dLit + i] = (u8)rleByte;
+                            else for (u32 i = 0; i < ll; i++) out[dLit + i] = lit[sLit + i];
+                        }
+                        u64 lm = ballot(have && longLit);
+                        while (lm) {
+                            const u32 i = ctz64(lm); lm &= lm - 1;
+                            const u32 d0 = read_lane(dLit, i), s0 = read_lane(sLit, i), n0 = read_lane(ll, i);
+                            if (litIsRle) { for (u32 k2 = lane; k2 < n0; k2 += 64) out[d0 + k2] = (u8)rleByte; }
+                            else wave_copy(out + d0, lit + s0, n0, lane);
+                        }
                     }
-                    wave_match_copy(out + op, offset, matchLength, lane);
-                    op += matchLength;
+                    // matches whose source was complete before this batch: one lane each
+                    const u32 srcEnd = dMatch - off + (off < ml ? off : ml);
+                    const bool indep = have && srcEnd <= op && ml <= 32;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // output of earlier batches (and this batch's literals) visible
+                    if (indep) { const u8* s0 = out + dMatch - off; if (off >= ml) { for (u32 i = 0; i < ml; i++) out[dMatch + i] = s0[i]; } else { for (u32 i = 0; i < ml; i++) out[dMatch + i] = s0[i % off]; } }
+                    // the others in sequence order, 64 lanes per match
+                    u64 dm = ballot(have && !indep && ml != 0);
+                    if (dm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    while (dm) {
+                        const u32 i = ctz64(dm); dm &= dm - 1;
+                        const u32 d0 = read_lane(dMatch, i), o0 = read_lane(off, i), n0 = read_lane(ml, i);
+                        wave_match_copy(out + d0, o0, n0, lane);
+                        if (dm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    }
+                    op += totalOut; litPos += totalLit;
                 }
                 u32 leftover = 0;
-                if (lane == 0) leftover = bd.pos > 0;
+                if (lane == 0) leftover = bd.remaining() > 0;
                 if (uniform(leftover)) FAIL(kErrCorruption);          // bitstream not fully consumed (:2730-2733)
             }
             {
                 const u32 lastLL = litSize - litPos;
                 if (lastLL > fd.dstSize - op) FAIL(kErrCorruption);
-                copy_literals(op, litPos, lastLL);
+                if (litIsRle) { for (u32 i = lane; i < lastLL; i += 64) out[op + i] = (u8)rleByte; }
+                else wave_copy(out + op, lit + litPos, lastLL, lane);
                 op += lastLL;
             }
             ip += bsz;

@@ -52,8 +52,9 @@ struct LzLds {
     u32 wordRank[kGroups + 1];           // selected matches before each group
     u32 endOf[kTilePos / 4 + 2];         // endOf[r+1] = absolute end of the r-th selected match of the tile; endOf[0] = anchor
     u32 waveCnt[2][16];
-    u64 nzWords;                         // bit g = matchMask[g] != 0
-    u32 cursor, anchor, nbSeq, litBase;
+    u64 nzWords;                         // bit g = matchMask[g] != 0 (accumulated with atomicOr during the probe, reset per tile)
+    u32 matchCount;                      // matches in the current tile (decides sparse / dense selection)
+    u16 sparseList[64];                  // sparse path: the tile's matches in position order
 };
 
 __device__ __forceinline__ u32 hash6(u64 w) { return (u32)(((w << 16) * 227718039650203ULL) >> (64 - kHashLog)); }
@@ -113,11 +114,48 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     for (u32 i = tid; i < (1u << kHashLog); i += kTile) { L.table[i] = 0; L.first[i] = 0xFFFFFFFFu; }
-    if (tid == 0) { L.cursor = 0; L.anchor = 0; L.nbSeq = 0; L.litBase = 0; }
+    if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }
     __syncthreads();
 
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
     u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
+    // parse state, kept identically in every thread's registers (all updates come from LDS values read after a barrier)
+    u32 cursor = 0;      // absolute position where the parse of the previous tiles ended (= end of the last selected match)
+    u32 nbSeq = 0, litBase = 0;
+
+    // one selected match -> its sequence + its coverage bits (used by the dense and the sparse path)
+    auto emit_match = [&](u32 tileStart, u32 q, u32 rank, u32 end) {
+        u32 p = tileStart + q;
+        const u32 off = L.tileOff[q];
+        const u32 litStart = L.endOf[rank];
+        const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
+        // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
+        while (p > floorPos && p > off && L.in[p - 1] == L.in[p - off - 1]) --p;
+        Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(p - litStart); sq.mlBase = (u16)(end - p - 3);
+        seqOut[nbSeq + rank] = sq;
+        const u32 r0 = p - tileStart, r1 = (end - tileStart) < kTilePos ? (end - tileStart) : kTilePos;
+        for (u32 wI = r0 >> 6; wI <= ((r1 - 1) >> 6); ++wI) {
+            u64 m = ~0ull;
+            if (wI == (r0 >> 6)) m &= ~0ull << (r0 & 63);
+            if (wI == ((r1 - 1) >> 6)) m &= ~0ull >> (63 - ((r1 - 1) & 63));
+            atomicOr((unsigned long long*)&L.covMask[wI], (unsigned long long)m);
+        }
+    };
+    // full length of a match that hit the cap: 64 lanes x 8 bytes per step (whole wave, uniform arguments)
+    auto finish_capped = [&](u32 p, u32 off) -> u32 {
+        u32 e = p + kLenCap;
+        for (;;) {
+            const u32 pos = e + 8 * lane;              // reads past n land in the table region: harmless, clamped below
+            const u64 x = readLE64(L.in + pos) ^ readLE64(L.in + pos - off);
+            const u64 bad = ballot(x != 0 || pos + 8 > n);
+            if (bad == 0) { e += 512; continue; }
+            const u32 fl = ctz64(bad);
+            const u32 cnt = x ? (ctz64(x) >> 3) : 8;
+            e += 8 * fl + read_lane(cnt, fl);
+            break;
+        }
+        return e > n ? n : e;
+    };
 
     // Matches may start where 8 bytes are still readable (the reference stops at iend-8, ZstdFast.cs:110).
     const u32 nTiles = (n + kTilePos - 1) / kTilePos;
@@ -169,18 +207,19 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
             }
             L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off;
             const u64 mm = ballot(len != 0), cm = ballot(len == kLenCap);
-            if (lane == 0) { L.matchMask[j * 16 + wave] = mm; L.capMask[j * 16 + wave] = cm; L.selMask[j * 16 + wave] = 0; }
+            if (lane == 0) {
+                const u32 g = j * 16 + wave;
+                L.matchMask[g] = mm; L.capMask[g] = cm; L.selMask[g] = 0; L.covMask[g] = 0;
+                if (mm) { atomicOr((unsigned long long*)&L.nzWords, 1ull << g); atomicAdd(&L.matchCount, popc64(mm)); }
+            }
         }
         __syncthreads();
-        // ---------------- select: orbit of the greedy parse by pointer doubling ----------------
-        if (wave == 0) {
-            const u64 nz = ballot(L.matchMask[lane] != 0);
-            if (lane == 0) L.nzWords = nz;
-        }
-        __syncthreads();
-        const u32 cursor = L.cursor;            // absolute position where the previous tiles' parse ended
-        const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;
-        if (L.nzWords != 0 && c0 < kTilePos) {  // (uniform) something to select in this tile
+        const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
+        const u32 matchCount = L.matchCount;
+        const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
+        const bool dense = any && matchCount > 64;
+        if (dense) {
+            // ---------------- select: orbit of the greedy parse by pointer doubling ----------------
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) {
                 const u32 q = j * kTile + tid;
@@ -207,14 +246,14 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                         }
                     }
                 }
-                const int any = __syncthreads_or((int)added);     // all reads of jump[] done; did the orbit grow?
+                const int grew = __syncthreads_or((int)added);    // all reads of jump[] done; did the orbit grow?
 #pragma unroll
                 for (u32 j = 0; j < kPPT; ++j) { const u32 q = j * kTile + tid; if (L.tileLen[q]) L.jump[q] = (u16)nv[j]; }
                 __syncthreads();
-                if (!any) break;
+                if (!grew) break;
             }
-            // ---------------- finish capped matches in order; drop the selections they swallow (wave 0) ----------------
             if (wave == 0) {
+                // ---- finish capped matches in order; drop the selections they swallow ----
                 u32 from = 0;                  // consider selected capped matches at tile positions >= from
                 while (from < kTilePos) {
                     u64 wm = L.selMask[lane] & L.capMask[lane];       // lane = group index; re-read every time
@@ -223,19 +262,8 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                     if (!have) break;
                     const u32 g = ctz64(have);
                     const u32 q = g * 64 + ctz64(read_lane64(wm, g));
-                    const u32 p = tileStart + q, off = L.tileOff[q];
-                    u32 e = p + kLenCap;
-                    for (;;) {
-                        const u32 pos = e + 8 * lane;              // reads past n land in the table region: harmless, clamped below
-                        const u64 x = readLE64(L.in + pos) ^ readLE64(L.in + pos - off);
-                        const u64 bad = ballot(x != 0 || pos + 8 > n);
-                        if (bad == 0) { e += 512; continue; }
-                        const u32 fl = ctz64(bad);
-                        const u32 cnt = x ? (ctz64(x) >> 3) : 8;
-                        e += 8 * fl + read_lane(cnt, fl);
-                        break;
-                    }
-                    if (e > n) e = n;
+                    const u32 p = tileStart + q;
+                    const u32 e = finish_capped(p, L.tileOff[q]);
                     if (lane == 0) L.jump[q] = (u16)(e - p > 0xFFFFu ? 0xFFFFu : e - p);
                     const u32 r0 = q + 1, r1 = (e - tileStart) < kTilePos ? (e - tileStart) : kTilePos;   // swallowed: [r0, r1)
                     if (r1 > r0) {
@@ -250,58 +278,66 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                     }
                     from = r1 > r0 ? r1 : r0;
                 }
+                // ---- ranks: selected matches before each group ----
+                const u32 cnt = popc64(L.selMask[lane]);
+                const u32 incl = wave_scan_incl(cnt);
+                L.wordRank[lane] = incl - cnt;
+                if (lane == 63) L.wordRank[64] = incl;
+                if (lane == 0) L.endOf[0] = cursor;
             }
             __syncthreads();
-        }
-        // ---------------- emit ----------------
-        if (wave == 0) {        // ranks: selected matches before each group
-            const u32 cnt = popc64(L.selMask[lane]);
-            const u32 incl = wave_scan_incl(cnt);
-            L.wordRank[lane] = incl - cnt;
-            if (lane == 63) L.wordRank[64] = incl;
-            if (lane == 0) L.endOf[0] = L.anchor;
-            L.covMask[lane] = 0;
-        }
+            u32 myRank[kPPT], myEnd[kPPT]; bool sel[kPPT];
+#pragma unroll
+            for (u32 j = 0; j < kPPT; ++j) {
+                const u32 q = j * kTile + tid;
+                const u64 sm = L.selMask[q >> 6];
+                sel[j] = (sm >> (q & 63)) & 1ull;
+                myRank[j] = 0; myEnd[j] = 0;
+                if (sel[j]) {
+                    myRank[j] = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
+                    const u32 len = L.tileLen[q];
+                    myEnd[j] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
+                    L.endOf[myRank[j] + 1] = myEnd[j];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (u32 j = 0; j < kPPT; ++j) if (sel[j]) emit_match(tileStart, j * kTile + tid, myRank[j], myEnd[j]);
+        } else if (any) {
+            // ---------------- sparse tile (<= 64 matches): wave 0 parses it alone, exactly greedy ----------------
+            if (wave == 0) {
+                {   // the tile's matches in position order -> one per lane
+                    const u64 mmw = L.matchMask[lane];
+                    const u32 cnt = popc64(mmw);
+                    u32 r = wave_scan_incl(cnt) - cnt;
+                    for (u64 b = mmw; b; b &= b - 1) L.sparseList[r++] = (u16)(lane * 64 + ctz64(b));
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                const bool have = lane < matchCount;
+                const u32 q = have ? L.sparseList[lane] : 0;
+                const u32 len = have ? L.tileLen[q] : 0, off = have ? L.tileOff[q] : 0;
+                u32 myEnd = 0; u64 selBits = 0; u32 cur = c0, lastEnd = cursor;
+                for (u32 i = 0; i < matchCount; ++i) {
+                    const u32 qi = read_lane(q, i);
+                    if (qi < cur) continue;
+                    const u32 li = read_lane(len, i);
+                    u32 e = tileStart + qi + li;
+                    if (li == kLenCap) e = finish_capped(tileStart + qi, read_lane(off, i));
+                    if (lane == i) myEnd = e;
+                    selBits |= 1ull << i;
+                    cur = e - tileStart; lastEnd = e;
+                }
+                const bool sel = (selBits >> lane) & 1ull;
+                const u32 rank = popc64(selBits & lanemask_lt());
+                const u32 nSel = popc64(selBits);
+                if (lane == 0) { L.endOf[0] = cursor; L.wordRank[64] = nSel; }
+                if (sel) L.endOf[rank + 1] = myEnd;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                if (sel) emit_match(tileStart, q, rank, myEnd);
+            }
+        } else if (tid == 0) L.wordRank[64] = 0;
         __syncthreads();
         const u32 nSel = L.wordRank[64];
-        const u32 nbSeqBase = L.nbSeq;
-        u32 myRank[kPPT], myEnd[kPPT]; bool sel[kPPT];
-#pragma unroll
-        for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid;
-            const u64 sm = L.selMask[q >> 6];
-            sel[j] = (sm >> (q & 63)) & 1ull;
-            myRank[j] = 0; myEnd[j] = 0;
-            if (sel[j]) {
-                myRank[j] = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
-                const u32 len = L.tileLen[q];
-                myEnd[j] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
-                L.endOf[myRank[j] + 1] = myEnd[j];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (u32 j = 0; j < kPPT; ++j) {
-            if (!sel[j]) continue;
-            const u32 q = j * kTile + tid;
-            u32 p = tileStart + q;
-            const u32 off = L.tileOff[q];
-            const u32 litStart = L.endOf[myRank[j]];
-            const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
-            // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
-            while (p > floorPos && p > off && L.in[p - 1] == L.in[p - off - 1]) --p;
-            Seq s; s.offBase = off + 3; s.litLength = (u16)(p - litStart); s.mlBase = (u16)(myEnd[j] - p - 3);
-            seqOut[nbSeqBase + myRank[j]] = s;
-            // coverage inside this tile
-            const u32 r0 = p - tileStart, r1 = (myEnd[j] - tileStart) < kTilePos ? (myEnd[j] - tileStart) : kTilePos;
-            for (u32 wI = r0 >> 6; wI <= ((r1 - 1) >> 6); ++wI) {
-                u64 m = ~0ull;
-                if (wI == (r0 >> 6)) m &= ~0ull << (r0 & 63);
-                if (wI == ((r1 - 1) >> 6)) m &= ~0ull >> (63 - ((r1 - 1) & 63));
-                atomicOr((unsigned long long*)&L.covMask[wI], (unsigned long long)m);
-            }
-        }
-        __syncthreads();
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
         {
             const u32 q16 = tid * 16;              // 256 threads cover the tile, 16 positions each
@@ -317,14 +353,15 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
             }
             const u32 cnt = __builtin_popcount(keep);
             const u32 incl = wave_scan_incl(cnt);
-            if (lane == 63) L.waveCnt[t & 1][wave] = incl;
+            if (lane == 63 && wave < 4) L.waveCnt[t & 1][wave] = incl;
+            const u32 lastEnd = nSel ? L.endOf[nSel] : cursor;
             __syncthreads();
             u32 before = 0, total = 0;
 #pragma unroll
             for (u32 k = 0; k < 4; ++k) { const u32 v = L.waveCnt[t & 1][k]; total += v; if (k < wave) before += v; }
             if (tid < kTilePos / 16 && keep) {
                 const u32 p = tileStart + q16;
-                u8* o = litOut + L.litBase + before + incl - cnt;
+                u8* o = litOut + litBase + before + incl - cnt;
                 if (keep == 0xFFFFu) {
                     const uint4 v = *reinterpret_cast<const uint4*>(L.in + p);
                     *(u32u*)(o) = v.x; *(u32u*)(o + 4) = v.y; *(u32u*)(o + 8) = v.z; *(u32u*)(o + 12) = v.w;
@@ -332,17 +369,13 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                     while (keep) { const u32 k = __builtin_ctz(keep); keep &= keep - 1; *o++ = L.in[p + k]; }
                 }
             }
-            __syncthreads();
-            if (tid == 0) {
-                L.litBase += total;
-                if (nSel) { const u32 e = L.endOf[nSel]; L.anchor = e; L.cursor = e; L.nbSeq = nbSeqBase + nSel; }
-            }
-            __syncthreads();
+            litBase += total; nbSeq += nSel; cursor = lastEnd;
+            if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }     // next tile's probe phase sits behind its own barrier
         }
     }
     if (tid == 0) {
         ChunkMeta m = {};
-        m.srcSize = n; m.nbSeq = L.nbSeq; m.litSize = L.litBase; m.fhSize = frame_header_size(n);
+        m.srcSize = n; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(n);
         meta[c] = m;
     }
 }
