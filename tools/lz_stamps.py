@@ -1,0 +1,22 @@
+"""Diagnostic: phase shares of lz_fast_kernel from the stamped build (make -C zstdsharp_amd/csrc stamps)."""
+import sys, os, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch, datagen, numpy as np
+import zstdsharp_amd._ffi as ffi
+ffi.LIB_PATH = os.path.join(ROOT, "zstdsharp_amd", "libzstd_mi355x_stamps.so")
+lib = ffi.load()
+raw = ctypes.CDLL(ffi.LIB_PATH); raw.ZSTDMI_debugReadLzStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "select+emit", "barrier C", "literals"]
+n = 256 << 20
+for kind in ("zipf", "text"):
+    host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), 8)[:n]
+    src = torch.from_numpy(host.copy()).cuda(); torch.cuda.synchronize()
+    cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
+    c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, 1)
+    lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
+    buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1)
+    lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
+    raw.ZSTDMI_debugReadLzStamps(buf, 1)
+    tot = sum(buf[i] for i in range(8)); chunks = n // 65536
+    print(kind, "cycles/chunk", tot // chunks, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)

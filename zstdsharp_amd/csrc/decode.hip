@@ -765,7 +765,7 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 la
 // are fetched one re-base ahead.  Bytes outside the stream read as zero (the reference's overflow behaviour).
 struct SeqBits {
     const u8* s; s32 size, ptr, lp; u64 cont, raw; u32 consumed;
-    __device__ __forceinline__ u64 load8z(s32 idx) const
+    __device__ __forceinline__ u64 load8z(s32 idx) const      // slow, exact: zeros outside [0, size)
     {
         if (idx >= 0 && idx + 8 <= size) return readLE64(s + idx);
         u64 v = 0;
@@ -783,13 +783,16 @@ struct SeqBits {
         consumed = 64u - (u32)(remaining - 8 * ptr);
         return true;
     }
-    __device__ __forceinline__ void rebase()           // afterwards consumed <= 7: up to 57 bits can be read
+    // afterwards consumed <= 7: up to 57 bits can be read.  Branch-free for streams of >= 16 bytes so that the prefetch
+    // load is waited for only where `raw` is next used (one sequence later).
+    __device__ __forceinline__ void rebase()
     {
         const u32 k = consumed >> 3;
-        if (k) {
-            cont = k >= 8 ? raw : ((cont << (8 * k)) | (raw >> (64 - 8 * k)));
-            ptr -= (s32)k; consumed -= 8 * k; lp = ptr - 8; raw = load8z(lp);
-        }
+        const u64 lower = size >= 16 ? (lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0)) : raw;
+        cont = k == 0 ? cont : (k >= 8 ? lower : ((cont << (8 * k)) | (lower >> (64 - 8 * k))));
+        ptr -= (s32)k; consumed -= 8 * k; lp = ptr - 8;
+        if (size >= 16) raw = readLE64(s + (lp > 0 ? lp : 0));       // uniform branch (size is fixed per stream)
+        else raw = load8z(lp);
     }
     __device__ __forceinline__ u32 read(u32 nb) { const u32 v = nb ? (u32)((cont << consumed) >> (64 - nb)) : 0u; consumed += nb; return v; }
     __device__ __forceinline__ s32 remaining() const { return 8 * ptr + 64 - (s32)consumed; }
@@ -903,7 +906,7 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                             }
                             if (ml.nbAddBits) matchLength += bd.read(ml.nbAddBits);
                             if (ll.nbAddBits) litLength += bd.read(ll.nbAddBits);
-                            bd.rebase();
+                            if (bd.consumed > 64 - 26) bd.rebase();      // rare: long extra-bit fields; the three state reads need <= 26 bits
                             sLL = ll.nextState + bd.read(ll.nbBits);
                             sML = ml.nextState + bd.read(ml.nbBits);
                             sOF = of.nextState + bd.read(of.nbBits);

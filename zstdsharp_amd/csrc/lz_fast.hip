@@ -27,6 +27,14 @@
 
 namespace zmi {
 
+#ifdef ZMI_LZ_STAMPS
+// diagnostic build only (make STAMPS=1): per-phase shader-clock sums of thread 0 of every workgroup
+__device__ unsigned long long g_lzStamps[16];
+#define ZMI_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
+#else
+#define ZMI_STAMP(i) do { } while (0)
+#endif
+
 constexpr u32 kHashLog  = 13;            // the reference's hashLog for level 1 at <= 128 KiB (U/Clevels.cs:488)
 constexpr u32 kTile     = 1024;          // threads per workgroup
 constexpr u32 kPPT      = 4;             // positions per thread per tile
@@ -101,6 +109,9 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
     const u64 base = (u64)c << kChunkLog;
     const u32 n = (u32)((srcSize - base) < kChunkSize ? (srcSize - base) : kChunkSize);
     const u8* __restrict__ in = src + base;
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- stage the chunk: 16 B per lane when the source is 16-byte aligned ----
     if ((((uintptr_t)in) & 15) == 0) {
@@ -116,6 +127,7 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
     for (u32 i = tid; i < (1u << kHashLog); i += kTile) { L.table[i] = 0; L.first[i] = 0xFFFFFFFFu; }
     if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }
     __syncthreads();
+    ZMI_STAMP(0);
 
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
     u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
@@ -170,7 +182,9 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
             valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cand[j] = 0;
             if (valid[j]) { w[j] = readLE64(L.in + p); h[j] = hash6(w[j]); cand[j] = L.table[h[j]]; atomicMin(&L.first[h[j]], stamp | q); }
         }
+        ZMI_STAMP(1);
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
+        ZMI_STAMP(2);
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = j * kTile + tid, p = tileStart + q;
@@ -213,7 +227,9 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                 if (mm) { atomicOr((unsigned long long*)&L.nzWords, 1ull << g); atomicAdd(&L.matchCount, popc64(mm)); }
             }
         }
+        ZMI_STAMP(3);
         __syncthreads();
+        ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
         const u32 matchCount = L.matchCount;
         const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
@@ -336,7 +352,9 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                 if (sel) emit_match(tileStart, q, rank, myEnd);
             }
         } else if (tid == 0) L.wordRank[64] = 0;
+        ZMI_STAMP(5);
         __syncthreads();
+        ZMI_STAMP(6);
         const u32 nSel = L.wordRank[64];
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
         {
@@ -372,7 +390,11 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
             litBase += total; nbSeq += nSel; cursor = lastEnd;
             if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }     // next tile's probe phase sits behind its own barrier
         }
+        ZMI_STAMP(7);
     }
+#ifdef ZMI_LZ_STAMPS
+    if (tid == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
+#endif
     if (tid == 0) {
         ChunkMeta m = {};
         m.srcSize = n; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(n);
@@ -381,6 +403,14 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
 }
 
 size_t lz_fast_lds_bytes() { return sizeof(LzLds); }
+
+#ifdef ZMI_LZ_STAMPS
+extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
+{
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lzStamps), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzStamps), z, sizeof z); }
+}
+#endif
 
 void launch_lz_fast(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
 {

@@ -37,6 +37,10 @@ struct SeqWaveLds {
     u16 llState[512]; u16 mlState[512]; u16 ofState[256];
     SymTT llTT[36]; SymTT mlTT[53]; SymTT ofTT[32];
     s16 norm[64]; u16 cumul[66]; u8 tableSymbol[512];
+    // one batch of 64 sequences: codes in, (state bits, count) out of the three chains, and the packing tile
+    u8  bCode[3][64];
+    u32 bBits[3][64];                   // low 16: value, high 16: number of bits
+    u32 tile[192];
 };
 
 struct SeqTable { const u16* state; const SymTT* tt; u32 tableLog; };
@@ -140,17 +144,17 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
-    if (lane != 0) return;
 
-    // ---------------- serial section: one lane ----------------
+    // ---------------- serial section (lane 0): section header + the three table descriptions ----------------
     u8* op = body + m.litSectionSize;
     bool giveUp = n < 7;                 // ZSTD_buildSeqStore: blocks under MIN_CBLOCK_SIZE+header are never compressed
-    if (!giveUp) {
+    u32 bodyTablesEnd = 0, typesOk = 0, tLLlog = 0, tOFlog = 0, tMLlog = 0, tLastCount = 0;
+    if (lane == 0 && !giveUp) {
         if (nbSeq < 128) *op++ = (u8)nbSeq;
         else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
         else { op[0] = 0xFF; writeLE16(op + 1, nbSeq - 0x7F00); op += 3; }
     }
-    if (!giveUp && nbSeq) {
+    if (lane == 0 && !giveUp && nbSeq) {
         u8* const seqHead = op++;
         const Seq last = sq[nbSeq - 1];
         const u32 lastLL = ll_code(last.litLength), lastOF = highbit32(last.offBase), lastML = ml_code(last.mlBase);
@@ -161,28 +165,101 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
         // lastCountSize must be the size of the LAST compressed table description (U/ZstdCompress.cs:3196-3224)
         *seqHead = (u8)((LLtype << 6) + (OFtype << 4) + (MLtype << 2));
 
-        // ZSTD_encodeSequences_body
-        BitW bw; bw.init(op);
-        u32 sLL = fse_init_state2(W.llState, W.llTT, lastLL);
-        u32 sOF = fse_init_state2(W.ofState, W.ofTT, lastOF);
-        u32 sML = fse_init_state2(W.mlState, W.mlTT, lastML);
-        bw.add(last.litLength, cLL_bits[lastLL]);
-        bw.add(last.mlBase, cML_bits[lastML]);
-        bw.add(last.offBase, lastOF);
-        for (u32 i = nbSeq - 1; i-- > 0; ) {
-            const Seq s = sq[i];
-            const u32 ll = ll_code(s.litLength), of = highbit32(s.offBase), ml = ml_code(s.mlBase);
-            { const SymTT t = W.ofTT[of]; const u32 nb = (sOF + t.deltaNbBits) >> 16; bw.add(sOF, nb); sOF = W.ofState[(s32)(sOF >> nb) + t.deltaFindState]; }
-            { const SymTT t = W.mlTT[ml]; const u32 nb = (sML + t.deltaNbBits) >> 16; bw.add(sML, nb); sML = W.mlState[(s32)(sML >> nb) + t.deltaFindState]; }
-            { const SymTT t = W.llTT[ll]; const u32 nb = (sLL + t.deltaNbBits) >> 16; bw.add(sLL, nb); sLL = W.llState[(s32)(sLL >> nb) + t.deltaFindState]; }
-            bw.add(s.litLength, cLL_bits[ll]);
-            bw.add(s.mlBase, cML_bits[ml]);
-            bw.add(s.offBase, of);
+        bodyTablesEnd = (u32)(op - body);
+        typesOk = 1; tLLlog = llLog; tOFlog = ofLog; tMLlog = mlLog; tLastCount = lastCountSize;
+    }
+    // ---- hand the table geometry to the whole wave ----
+    bodyTablesEnd = uniform(bodyTablesEnd); typesOk = uniform(typesOk);
+    tLLlog = uniform(tLLlog); tOFlog = uniform(tOFlog); tMLlog = uniform(tMLlog); tLastCount = uniform(tLastCount);
+    u32 bitstreamSize = 0;
+    if (typesOk) {
+        // ZSTD_encodeSequences_body (U/ZstdCompressSequences.cs:585-704), 64 sequences per step, last sequence first:
+        //   lanes 0/1/2 run the LL / OF / ML state chains (they are independent of each other: a state only depends on
+        //   its own previous state and symbol), every lane then packs the bit fields of ONE sequence in the reference's
+        //   order [OF state, ML state, LL state, LL extra, ML extra, OF extra]; a wave prefix sum places them.
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        u8* const out = body + bodyTablesEnd;
+        const u16* const stT = lane == 0 ? W.llState : lane == 1 ? W.ofState : W.mlState;
+        const SymTT* const ttT = lane == 0 ? W.llTT : lane == 1 ? W.ofTT : W.mlTT;
+        u32 state = 0;
+        u32 carry = 0, carryBits = 0, outWords = 0;
+        for (u32 done = 0; done < nbSeq; done += 64) {
+            const u32 cnt = nbSeq - done < 64 ? nbSeq - done : 64;
+            const bool have = lane < cnt;
+            Seq sv; sv.offBase = 1; sv.litLength = 0; sv.mlBase = 0;
+            if (have) sv = sq[nbSeq - 1 - done - lane];
+            const u32 llc = ll_code(sv.litLength), ofc = highbit32(sv.offBase), mlc = ml_code(sv.mlBase);
+            W.bCode[0][lane] = (u8)llc; W.bCode[1][lane] = (u8)ofc; W.bCode[2][lane] = (u8)mlc;
+            for (u32 i = lane; i < 192; i += 64) W.tile[i] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            if (lane < 3) {
+                for (u32 k = 0; k < cnt; k++) {
+                    const u32 sym = W.bCode[lane][k];
+                    if (done == 0 && k == 0) { state = fse_init_state2(stT, ttT, sym); W.bBits[lane][k] = 0; }   // FSE_initCState2: no bits
+                    else {
+                        const SymTT tt = ttT[sym];
+                        const u32 nb = (state + tt.deltaNbBits) >> 16;
+                        W.bBits[lane][k] = (state & ((1u << nb) - 1)) | (nb << 16);
+                        state = stT[(s32)(state >> nb) + tt.deltaFindState];
+                    }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            u64 lo = 0, hi = 0; u32 nbTot = 0;
+            auto put = [&](u32 v, u32 nb) {
+                if (!nb) return;
+                const u64 vv = v & ((nb >= 32) ? 0xFFFFFFFFu : ((1u << nb) - 1));
+                if (nbTot < 64) { lo |= vv << nbTot; if (nbTot + nb > 64) hi |= vv >> (64 - nbTot); }
+                else hi |= vv << (nbTot - 64);
+                nbTot += nb;
+            };
+            if (have) {
+                const u32 bOF = W.bBits[1][lane], bML = W.bBits[2][lane], bLL = W.bBits[0][lane];
+                put(bOF & 0xFFFF, bOF >> 16); put(bML & 0xFFFF, bML >> 16); put(bLL & 0xFFFF, bLL >> 16);
+                put(sv.litLength, cLL_bits[llc]); put(sv.mlBase, cML_bits[mlc]); put(sv.offBase, ofc);
+            }
+            const u32 incl = wave_scan_incl(nbTot);
+            const u32 batchBits = read_lane(incl, 63);
+            const u32 bitOff = carryBits + incl - nbTot;
+            if (nbTot) {
+                const u32 w0 = bitOff >> 5, sh = bitOff & 31;
+                const u64 a0 = lo << sh;
+                const u64 a1 = sh ? ((lo >> (64 - sh)) | (hi << sh)) : hi;
+                const u32 a2 = sh ? (u32)(hi >> (64 - sh)) : 0;
+                atomicOr(&W.tile[w0], (u32)a0);
+                if ((u32)(a0 >> 32)) atomicOr(&W.tile[w0 + 1], (u32)(a0 >> 32));
+                if ((u32)a1) atomicOr(&W.tile[w0 + 2], (u32)a1);
+                if ((u32)(a1 >> 32)) atomicOr(&W.tile[w0 + 3], (u32)(a1 >> 32));
+                if (a2) atomicOr(&W.tile[w0 + 4], a2);
+            }
+            if (lane == 0 && carryBits) atomicOr(&W.tile[0], carry);
+            const u32 total = carryBits + batchBits;
+            const u32 fullWords = total >> 5;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            for (u32 i = lane; i < fullWords; i += 64) *(u32u*)(out + 4 * (outWords + i)) = W.tile[i];
+            carry = W.tile[fullWords]; carryBits = total & 31;
+            outWords += fullWords;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         }
-        bw.add(sML, mlLog); bw.add(sOF, ofLog); bw.add(sLL, llLog);
-        u8* const end = bw.close();
-        const u32 bitstreamSize = (u32)(end - op);
-        op = end;
+        // FSE_flushCState x3 (ML, OF, LL) + end mark (BIT_closeCStream)
+        const u32 stLL = read_lane(state, 0), stOF = read_lane(state, 1), stML = read_lane(state, 2);
+        if (lane == 0) {
+            u64 acc = carry; u32 nb = carryBits;
+            acc |= (u64)(stML & ((1u << tMLlog) - 1)) << nb; nb += tMLlog;
+            acc |= (u64)(stOF & ((1u << tOFlog) - 1)) << nb; nb += tOFlog;
+            acc |= (u64)(stLL & ((1u << tLLlog) - 1)) << nb; nb += tLLlog;
+            acc |= 1ull << nb; nb += 1;
+            u8* p = out + 4 * outWords;
+            const u32 nbytes = (nb + 7) >> 3;
+            for (u32 i = 0; i < nbytes; i++) { p[i] = (u8)acc; acc >>= 8; }
+            bitstreamSize = 4 * outWords + nbytes;
+        }
+        bitstreamSize = uniform(bitstreamSize);
+    }
+    if (lane != 0) return;
+    if (typesOk) {
+        op = body + bodyTablesEnd + bitstreamSize;
+        const u32 lastCountSize = tLastCount;
         if (lastCountSize && lastCountSize + bitstreamSize < 4) giveUp = true;      // 1.3.4 decoder quirk (:3346-3350)
     }
     u32 cSize = (u32)(op - body);
