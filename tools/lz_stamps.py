@@ -7,6 +7,8 @@ import zstdsharp_amd._ffi as ffi
 ffi.LIB_PATH = os.path.join(ROOT, "zstdsharp_amd", "libzstd_mi355x_stamps.so")
 lib = ffi.load()
 raw = ctypes.CDLL(ffi.LIB_PATH); raw.ZSTDMI_debugReadLzStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+raw.ZSTDMI_debugReadHufStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
 names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "select+emit", "barrier C", "literals"]
 n = 256 << 20
 for kind in ("zipf", "text"):
@@ -15,8 +17,11 @@ for kind in ("zipf", "text"):
     cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
-    buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1)
+    buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1); raw.ZSTDMI_debugReadHufStamps(buf, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     raw.ZSTDMI_debugReadLzStamps(buf, 1)
     tot = sum(buf[i] for i in range(8)); chunks = n // 65536
-    print(kind, "cycles/chunk", tot // chunks, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)
+    print(kind, "lz cycles/chunk", tot // chunks, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)
+    raw.ZSTDMI_debugReadHufStamps(buf, 1)
+    tot = sum(buf[i] for i in range(8))
+    print(kind, "huf_build cycles/chunk", tot // chunks, {hnames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)

@@ -19,6 +19,13 @@
 
 namespace zmi {
 
+#ifdef ZMI_LZ_STAMPS
+__device__ unsigned long long g_hufStamps[16];
+#define ZMI_HSTAMP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
+#else
+#define ZMI_HSTAMP(i) do { } while (0)
+#endif
+
 struct Node { u32 count; u16 parent; u8 byte; u8 nbBits; };
 
 struct HufBuildLds {
@@ -235,6 +242,9 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     const u32 litSize = m.litSize;
     const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
     const u32 lhSizeRaw = 1 + (litSize > 31) + (litSize > 4095);
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
 
     // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
     if (litSize <= 63) {
@@ -267,6 +277,7 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     }
     __syncthreads();
 
+    ZMI_HSTAMP(0);
     const u32 lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     const u32 single = litSize < 256;
     HufTable* T = tables + c;
@@ -282,19 +293,23 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
         L.sh[kShCompressed] = compressed; L.sh[kShMaxSV] = maxSV; L.sh[kShRle] = rle; L.sh[kShRleByte] = rleByte;
         if (compressed) huf_sort_place(L, maxSV);
     }
+    ZMI_HSTAMP(1);
     __syncthreads();
     const u32 maxSV = L.sh[kShMaxSV];
     if (L.sh[kShCompressed]) {
         if (tid < 26) huf_sort_bucket(L, tid);                 // HUF_sort's per-bucket quicksorts, one bucket per lane
         __syncthreads();
+        ZMI_HSTAMP(2);
         Node* huffNode = L.nodes + 1;
         if (tid == 0) { int root = 0; L.sh[kShNonNull] = (u32)huf_build_tree(huffNode, maxSV, &root); L.sh[kShRoot] = (u32)root; }
+        ZMI_HSTAMP(3);
         __syncthreads();
         {   // depth of every leaf = number of parent links up to the root (HUF_buildTree's nbBits loops)
             const u32 nonNull = L.sh[kShNonNull], root = L.sh[kShRoot];
             if (tid <= nonNull) { u32 node = tid, d = 0; while (node != root) { node = huffNode[node].parent; d++; } huffNode[tid].nbBits = (u8)d; }
         }
         __syncthreads();
+        ZMI_HSTAMP(4);
         if (tid == 0) {
             u32 huffLog = fse_optimal_table_log(11, litSize, maxSV, 1);
             const u32 nonNullRank = L.sh[kShNonNull];
@@ -306,6 +321,7 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
             L.valPerRank[0] = 0;
             L.sh[kShHuffLog] = huffLog;
         }
+        ZMI_HSTAMP(5);
         __syncthreads();
         const u32 huffLog = L.sh[kShHuffLog];
         if (tid <= maxSV) L.nbBits[huffNode[tid].byte] = huffNode[tid].nbBits;        // HUF_buildCTableFromTree
@@ -330,6 +346,7 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
             if (lane == 0) L.streamBits[wave] = bits;
         }
         __syncthreads();
+        ZMI_HSTAMP(6);
     }
     if (tid != 0) return;
 
@@ -378,7 +395,19 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
         m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize;
     }
     meta[c] = m;
+    ZMI_HSTAMP(7);
+#ifdef ZMI_LZ_STAMPS
+    for (int i = 0; i < 10; i++) atomicAdd(&g_hufStamps[i], stampAcc[i]);
+#endif
 }
+
+#ifdef ZMI_LZ_STAMPS
+extern "C" void ZSTDMI_debugReadHufStamps(unsigned long long* out16, int reset)
+{
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_hufStamps), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_hufStamps), z, sizeof z); }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------------
 constexpr u32 kSymPerLane = 8;

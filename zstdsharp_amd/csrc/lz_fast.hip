@@ -65,14 +65,31 @@ struct LzLds {
     u16 sparseList[64];                  // sparse path: the tile's matches in position order
 };
 
-__device__ __forceinline__ u32 hash6(u64 w) { return (u32)(((w << 16) * 227718039650203ULL) >> (64 - kHashLog)); }
+// hash of the 6 bytes at a position (the reference's ZSTD_hash6 needs a 64x64-bit multiply, four quarter-rate VALU
+// multiplies per lane; two 32-bit multiplies over the same six bytes mix as well for a 13-bit table)
+__device__ __forceinline__ u32 hash6(u64 w) { return ((u32)w * 2654435761u + ((u32)(w >> 32) & 0xFFFFu) * 2246822519u) >> (32 - kHashLog); }
 __device__ __forceinline__ u64 read_lane64(u64 v, u32 l) { return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32); }
+
+// 8 / 4 input bytes at an arbitrary LDS position, fetched as ALIGNED dwords + v_alignbyte: consecutive lanes read
+// consecutive positions, so four lanes share each dword (broadcast, conflict-free), which an unaligned ds_read_b64
+// per lane is not
+__device__ __forceinline__ u64 lds_load8(const u8* base, u32 pos)
+{
+    const u32* w32 = reinterpret_cast<const u32*>(base) + (pos >> 2);
+    const u32 sh = pos & 3, d0 = w32[0], d1 = w32[1], d2 = w32[2];
+    return (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+}
+__device__ __forceinline__ u32 lds_load4(const u8* base, u32 pos)
+{
+    const u32* w32 = reinterpret_cast<const u32*>(base) + (pos >> 2);
+    return __builtin_amdgcn_alignbyte(w32[1], w32[0], pos & 3);
+}
 
 // length of the match between position p (its first 8 bytes are w) and cpos < p, capped; 0 if shorter than 4
 __device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w, u32 n)
 {
-    u64 x = w ^ readLE64(L.in + cpos);
-    if ((u32)x != 0) return 0;
+    if (lds_load4(L.in, cpos) != (u32)w) return 0;          // the reference's MEM_read32 check (ZstdFast.cs:179-191)
+    u64 x = w ^ lds_load8(L.in, cpos);
     u32 l = x ? (ctz64(x) >> 3) : 8;
     if (!x) {
         while (l < kLenCap) {
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = j * kTile + tid, p = tileStart + q;
             valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cand[j] = 0;
-            if (valid[j]) { w[j] = readLE64(L.in + p); h[j] = hash6(w[j]); cand[j] = L.table[h[j]]; atomicMin(&L.first[h[j]], stamp | q); }
+            if (valid[j]) { w[j] = lds_load8(L.in, p); h[j] = hash6(w[j]); cand[j] = L.table[h[j]]; atomicMin(&L.first[h[j]], stamp | q); }
         }
         ZMI_STAMP(1);
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
@@ -194,14 +211,16 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                 // (1) periods 1..4: bytes p..p+7 repeat with period d and the d bytes before p agree — runs and tiny
                 //     patterns, which neither table can see inside one tile
                 u32 per = 0;
-                if (p >= 4) {
-                    const u32 prev4 = readLE32(L.in + p - 4);
-#pragma unroll
-                    for (u32 d = 4; d >= 1; --d) {
-                        const u64 m = (1ull << (64 - 8 * d)) - 1;
-                        const bool inner = ((w[j] >> (8 * d)) & m) == (w[j] & m);
-                        const bool lead = (prev4 >> (8 * (4 - d))) == (u32)(w[j] & ((1ull << (8 * d)) - 1));
-                        if (inner && lead) per = d;
+                {
+                    const u64 ww = w[j];
+                    const bool i1 = ((ww ^ (ww >> 8)) << 8) == 0, i2 = ((ww ^ (ww >> 16)) << 16) == 0,
+                               i3 = ((ww ^ (ww >> 24)) << 24) == 0, i4 = ((ww ^ (ww >> 32)) << 32) == 0;
+                    if ((i1 | i2 | i3 | i4) && p >= 4) {           // rare outside runs: only then look at the bytes before p
+                        const u32 prev4 = lds_load4(L.in, p - 4);
+                        if (i4 && prev4 == (u32)ww) per = 4;
+                        if (i3 && (prev4 >> 8) == ((u32)ww & 0xFFFFFFu)) per = 3;
+                        if (i2 && (prev4 >> 16) == ((u32)ww & 0xFFFFu)) per = 2;
+                        if (i1 && (prev4 >> 24) == ((u32)ww & 0xFFu)) per = 1;
                     }
                 }
                 if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
@@ -358,34 +377,27 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
         const u32 nSel = L.wordRank[64];
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
         {
-            const u32 q16 = tid * 16;              // 256 threads cover the tile, 16 positions each
+            const u32 q4 = tid * 4;                // 1024 threads cover the tile, 4 positions each
+            const u32 p = tileStart + q4;
             u32 keep = 0;
-            if (tid < kTilePos / 16) {
-                const u32 p = tileStart + q16;
-                if (p < n) {
-                    const u32 covw = (u32)(L.covMask[q16 >> 6] >> (q16 & 63));
-                    keep = ~covw & 0xFFFFu;
-                    if (n - p < 16) keep &= (1u << (n - p)) - 1;
-                    if (c0 > q16) keep &= (c0 - q16 >= 16) ? 0u : (0xFFFFu << (c0 - q16));     // before the entry cursor: inside an earlier match
-                }
+            if (p < n) {
+                keep = ~(u32)(L.covMask[q4 >> 6] >> (q4 & 63)) & 0xFu;
+                if (n - p < 4) keep &= (1u << (n - p)) - 1;
+                if (c0 > q4) keep &= (c0 - q4 >= 4) ? 0u : (0xFu << (c0 - q4));      // before the entry cursor: inside an earlier match
             }
             const u32 cnt = __builtin_popcount(keep);
             const u32 incl = wave_scan_incl(cnt);
-            if (lane == 63 && wave < 4) L.waveCnt[t & 1][wave] = incl;
+            if (lane == 63) L.waveCnt[t & 1][wave] = incl;
             const u32 lastEnd = nSel ? L.endOf[nSel] : cursor;
             __syncthreads();
             u32 before = 0, total = 0;
 #pragma unroll
-            for (u32 k = 0; k < 4; ++k) { const u32 v = L.waveCnt[t & 1][k]; total += v; if (k < wave) before += v; }
-            if (tid < kTilePos / 16 && keep) {
-                const u32 p = tileStart + q16;
+            for (u32 k = 0; k < 16; ++k) { const u32 v = L.waveCnt[t & 1][k]; total += v; if (k < wave) before += v; }
+            if (keep) {
                 u8* o = litOut + litBase + before + incl - cnt;
-                if (keep == 0xFFFFu) {
-                    const uint4 v = *reinterpret_cast<const uint4*>(L.in + p);
-                    *(u32u*)(o) = v.x; *(u32u*)(o + 4) = v.y; *(u32u*)(o + 8) = v.z; *(u32u*)(o + 12) = v.w;
-                } else {
-                    while (keep) { const u32 k = __builtin_ctz(keep); keep &= keep - 1; *o++ = L.in[p + k]; }
-                }
+                const u32 v = *reinterpret_cast<const u32*>(L.in + p);
+                if (keep == 0xFu) *(u32u*)o = v;
+                else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
             }
             litBase += total; nbSeq += nSel; cursor = lastEnd;
             if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }     // next tile's probe phase sits behind its own barrier
