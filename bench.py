@@ -78,6 +78,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mib", type=int, default=1024, help="uncompressed bytes per GPU (MiB)")
     ap.add_argument("--input", default="zipf", choices=["zipf", "text"])
+    ap.add_argument("--level", type=int, default=1, help="compression level (BASELINE.json metric: 1; configs[3] uses 5)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather-v of compressed shards")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -99,17 +100,17 @@ def main():
 
     n = args.size_mib << 20
     if args.input == "zipf":
-        src = make_zipf(n, 1234 + rank, dev); workload = f"{args.size_mib} MiB Zipf(alpha=1.1) bytes per GPU, level 1 (ZSTD_fast), 64 KiB independent chunks"
+        src = make_zipf(n, 1234 + rank, dev); workload = f"{args.size_mib} MiB Zipf(alpha=1.1) bytes per GPU, level {args.level}, 64 KiB independent chunks"
     else:
         import datagen, numpy as np
         base = datagen.text_like(64 << 20, 7 + rank)
         src = torch.from_numpy(np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()).to(dev)
-        workload = f"{args.size_mib} MiB synthetic text (declared stand-in for Silesia dickens, absent offline), level 1, 64 KiB chunks"
+        workload = f"{args.size_mib} MiB synthetic text (declared stand-in for Silesia dickens, absent offline), level {args.level}, 64 KiB chunks"
     torch.cuda.synchronize()          # the library runs on its own stream: the input must be complete before the first call
     cap = lib.ZSTD_compressBound(n)
     dst = torch.empty(cap + 64, dtype=torch.uint8, device=dev)
     back = torch.empty(n, dtype=torch.uint8, device=dev)
-    c, d = z.Compressor(1, device=local), z.Decompressor(device=local)
+    c, d = z.Compressor(args.level, device=local), z.Decompressor(device=local)
     lib.ZSTDMI_CCtx_setProfiling(c.cctx, 1); lib.ZSTDMI_DCtx_setProfiling(d.dctx, 1)
     comm = torch.cuda.Stream(device=dev) if world > 1 and not args.no_gather else None
     gathered = None
@@ -166,7 +167,7 @@ def main():
         alg_bytes = (1.0 + ratio) * n                  # (1 + r) bytes per input byte, both directions
         achieved = alg_bytes / (allk[dom] * 1e-3) / 1e9
         line = {
-            "metric": "MB/s compress+decompress, level 1", "value": round(world * n / (elapsed / K) / 1e6, 1) if ok else None, "unit": "MB/s",
+            "metric": f"MB/s compress+decompress, level {args.level}", "value": round(world * n / (elapsed / K) / 1e6, 1) if ok else None, "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "chunk": 65536, "framing": "one zstd frame per chunk",

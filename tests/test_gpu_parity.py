@@ -266,3 +266,54 @@ def test_many_contexts_concurrently(gpu_lib):
             return d.Unwrap(c.Wrap(data)) == data
     with cf.ThreadPoolExecutor(8) as ex:
         assert all(ex.map(work, range(24)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# rows a-5 / a-6: the higher-level match finders (dual-hash for levels 3-5, + lazy deferral for levels >= 6)
+# ---------------------------------------------------------------------------------------------------------------
+LEVEL_KINDS = ["text", "zipf", "runs", "mixed", "period", "zeros", "rand", "bytei"]
+
+
+@pytest.mark.parametrize("level", [2, 3, 4, 5, 6, 9, 19])
+def test_levels_round_trip(gpu_lib, oracle, level):
+    """Every level's frames decode bit-exactly with the oracle (i.e. with the reference's decoder) and with the GPU decoder."""
+    with z.Compressor(level) as c, z.Decompressor() as d:
+        for kind in LEVEL_KINDS:
+            for n in (1, 9, 300, 4097, 65536, 65537, 200001):
+                data = datagen.gen(kind, n, n + level)
+                comp = c.Wrap(data)
+                assert len(comp) <= c.GetCompressBound(n)
+                assert oracle.decompress(comp, n) == data, (level, kind, n)
+                assert d.Unwrap(comp) == data, (level, kind, n)
+
+
+@pytest.mark.parametrize("level", [3, 5, 7])
+def test_level_finders_sequences_reconstruct_input(gpu_lib, level):
+    with z.Compressor(level) as c:
+        for kind in ("text", "mixed", "runs", "period"):
+            data = datagen.gen(kind, 65536 + 30000, 3)
+            c.Wrap(data)
+            for idx, (lo, hi) in enumerate([(0, 65536), (65536, len(data))]):
+                seqs, lits = _gpu_chunk(gpu_lib, c.cctx, idx)
+                assert _replay(seqs, lits, hi - lo) == data[lo:hi]
+                assert all(mlb + 3 >= 4 for _, _, mlb in seqs)
+
+
+def test_levels_buy_ratio(gpu_lib, oracle):
+    """More search effort must not lose ratio (small tolerance: the finders are heuristics), and each tier stays near the
+    reference's own result for that level on the same 64 KiB framing (doubleFast at 3, greedy row-hash at 5)."""
+    sizes = {}
+    for kind in ("text", "mixed", "bytei"):
+        data = datagen.gen(kind, 1 << 20, 21)
+        for level in (1, 3, 5, 7):
+            with z.Compressor(level) as c:
+                a = c.Wrap(data); b = c.Wrap(data)
+                assert a == b                                   # deterministic at every level
+                sizes[(kind, level)] = len(a)
+        assert sizes[(kind, 3)] <= sizes[(kind, 1)] * 1.005, (kind, sizes)
+        assert sizes[(kind, 5)] <= sizes[(kind, 3)] * 1.005, (kind, sizes)
+        assert sizes[(kind, 7)] <= sizes[(kind, 5)] * 1.005, (kind, sizes)
+        for level, slack in ((3, 1.08), (5, 1.12)):
+            ref = len(oracle.compress(data, level, 0, 65536))
+            assert sizes[(kind, level)] <= ref * slack + 64, (kind, level, sizes[(kind, level)], ref)
+    print("level sizes", sizes)

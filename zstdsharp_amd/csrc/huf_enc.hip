@@ -39,6 +39,8 @@ struct HufBuildLds {
     // FSE scratch for the weights (alphabet 0..12, tableLog <= 6)
     u32 wcount[13]; s16 wnorm[13]; u16 wstate[64]; SymTT wtt[13]; u16 wcumul[15]; u8 wsym[64];
     u32 sampleMax[2];
+    u32 redMaxSV[4], redLargest[4];
+    u8  sortIdx[256];
     int qsStack[26][64];        // one explicit quicksort stack per log2 bucket (buckets are sorted by separate lanes)
     u32 rankCnt[13][4];
     u32 valPerRank[13];
@@ -88,19 +90,7 @@ __device__ inline void huf_quick_sort(Node* a, int low0, int high0, int* stack)
     }
 }
 
-// bucket placement (serial, one lane); the log2 buckets are then sorted by huf_sort_bucket on separate lanes
-__device__ inline void huf_sort_place(HufBuildLds& L, u32 maxSV)
-{
-    Node* huffNode = L.nodes + 1;
-    const u32 maxSV1 = maxSV + 1;
-    for (u32 n = 0; n < 192; n++) { L.rankBase[n] = 0; L.rankCurr[n] = 0; }
-    for (u32 n = 0; n < maxSV1; n++) L.rankBase[huf_get_index(L.count[n])]++;
-    for (u32 n = 191; n > 0; n--) { L.rankBase[n - 1] += L.rankBase[n]; L.rankCurr[n - 1] = L.rankBase[n - 1]; }
-    for (u32 n = 0; n < maxSV1; n++) {
-        const u32 c = L.count[n], r = huf_get_index(c) + 1, pos = L.rankCurr[r]++;
-        huffNode[pos].count = c; huffNode[pos].byte = (u8)n;
-    }
-}
+// the log2 buckets (extents computed by the kernel's parallel placement) are sorted on separate lanes
 __device__ inline void huf_sort_bucket(HufBuildLds& L, u32 b /* 0..25 */)
 {
     const u32 n = 165 + b;
@@ -198,8 +188,7 @@ __device__ inline u32 huf_compress_weights(HufBuildLds& L, u8* dst, u32 wtSize)
 {
     u32 maxSV = 12;
     if (wtSize <= 1) return 0;
-    for (u32 s = 0; s <= 12; s++) L.wcount[s] = 0;
-    for (u32 i = 0; i < wtSize; i++) L.wcount[L.weights[i]]++;
+    // L.wcount = histogram of the weights, accumulated by the threads that produced them
     while (!L.wcount[maxSV]) maxSV--;
     u32 maxCount = 0;
     for (u32 s = 0; s <= maxSV; s++) if (L.wcount[s] > maxCount) maxCount = L.wcount[s];
@@ -255,11 +244,32 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     for (u32 i = tid; i < 2 * 256; i += 256) (&L.sample[0][0])[i] = 0;
     for (u32 i = tid; i < 513; i += 256) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
     L.nbBits[tid] = 0;
+    if (tid < 13) L.wcount[tid] = 0;
     __syncthreads();
     const u32 seg = (litSize + 3) / 4;
     {   // wave w counts segment w (these are also the per-stream histograms that size the four streams)
         const u32 s0 = wave * seg, s1 = (s0 + seg < litSize) ? s0 + seg : litSize;
-        for (u32 i = s0 + lane; i < s1; i += 64) atomicAdd(&L.hist[wave][lit[i]], 1u);
+        u32* H = L.hist[wave];
+        if (s0 < s1) {
+            // 16 bytes per lane per load (the literal buffer is 64 KiB-aligned): a byte-per-lane loop is bound by one
+            // global-load latency per 64 bytes
+            u32 a0 = (s0 + 15) & ~15u; if (a0 > s1) a0 = s1;
+            if (s0 + lane < a0) atomicAdd(&H[lit[s0 + lane]], 1u);
+            const u32 nVec = (s1 - a0) >> 4;
+            const uint4* v4 = reinterpret_cast<const uint4*>(lit + a0);
+#pragma unroll 2
+            for (u32 i = lane; i < nVec; i += 64) {
+                const uint4 v = v4[i];
+                const u32 d[4] = { v.x, v.y, v.z, v.w };
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) {
+                    atomicAdd(&H[d[k] & 0xFF], 1u); atomicAdd(&H[(d[k] >> 8) & 0xFF], 1u);
+                    atomicAdd(&H[(d[k] >> 16) & 0xFF], 1u); atomicAdd(&H[d[k] >> 24], 1u);
+                }
+            }
+            const u32 t0 = a0 + (nVec << 4);
+            if (t0 + lane < s1) atomicAdd(&H[lit[t0 + lane]], 1u);
+        }
     }
     const u32 suspect = (m.nbSeq == 0) || (litSize / m.nbSeq >= 20);
     const bool doSample = suspect && litSize >= 4096 * 10;
@@ -281,17 +291,37 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     const u32 lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
     const u32 single = litSize < 256;
     HufTable* T = tables + c;
-    if (tid == 0) {       // compressible at all?  (HUF_compress_internal, U/HufCompress.cs:1412-1462)
-        u32 compressed = 1, rle = 0, rleByte = 0, maxSV = 255, largest = 0;
-        if (doSample && L.sampleMax[0] + L.sampleMax[1] <= ((2 * 4096) >> 7) + 4) compressed = 0;
+    {   // compressible at all?  (HUF_compress_internal, U/HufCompress.cs:1412-1462) — every thread reaches the same verdict
+        const u32 cnt = L.count[tid];
+        const u64 nz = ballot(cnt != 0);
+        const u32 wmx = wave_max(cnt);
+        if (lane == 0) { L.redMaxSV[wave] = nz ? wave * 64 + 63 - (u32)__builtin_clzll(nz) : 0; L.redLargest[wave] = wmx; }
+        __syncthreads();
+        u32 maxSV0 = 0, largest = 0;
+        for (u32 w = 0; w < 4; ++w) { maxSV0 = L.redMaxSV[w] > maxSV0 ? L.redMaxSV[w] : maxSV0; largest = L.redLargest[w] > largest ? L.redLargest[w] : largest; }
+        u32 compressed = 1, rle = 0;
+        if (doSample && L.sampleMax[0] + L.sampleMax[1] <= ((2 * 4096) >> 7) + 4) { compressed = 0; maxSV0 = 255; }
+        else if (largest == litSize) { rle = 1; compressed = 0; }
+        else if (largest <= (litSize >> 7) + 4) compressed = 0;
+        if (tid == 0) { L.sh[kShCompressed] = compressed; L.sh[kShMaxSV] = maxSV0; L.sh[kShRle] = rle; L.sh[kShRleByte] = rle ? lit[0] : 0; }
         if (compressed) {
-            while (!L.count[maxSV]) maxSV--;
-            for (u32 s = 0; s <= maxSV; s++) if (L.count[s] > largest) largest = L.count[s];
-            if (largest == litSize) { rle = 1; rleByte = lit[0]; compressed = 0; }
-            else if (largest <= (litSize >> 7) + 4) compressed = 0;
+            // HUF_sort's bucket placement (U/HufCompress.cs:635-680) without the serial counters: a symbol lands behind
+            // every symbol of a higher bucket and behind the lower-numbered symbols of its own bucket
+            const u32 idx = huf_get_index(cnt);
+            L.sortIdx[tid] = (u8)idx;
+            __syncthreads();
+            if (tid <= maxSV0) {
+                u32 pos = 0;
+                for (u32 mS = 0; mS <= maxSV0; ++mS) { const u32 im = L.sortIdx[mS]; pos += (im > idx) || (im == idx && mS < tid); }
+                Node nd; nd.count = cnt; nd.parent = 0; nd.byte = (u8)tid; nd.nbBits = 0;
+                L.nodes[1 + pos] = nd;
+            }
+            if (tid < 26) {            // extent of log2 bucket n (symbols whose index is n-1), for huf_sort_bucket
+                const u32 nB = 165 + tid; u32 start = 0, size = 0;
+                for (u32 mS = 0; mS <= maxSV0; ++mS) { const u32 im = L.sortIdx[mS]; start += im >= nB; size += im == nB - 1; }
+                L.rankBase[nB] = (u16)start; L.rankCurr[nB] = (u16)(start + size);
+            }
         }
-        L.sh[kShCompressed] = compressed; L.sh[kShMaxSV] = maxSV; L.sh[kShRle] = rle; L.sh[kShRleByte] = rleByte;
-        if (compressed) huf_sort_place(L, maxSV);
     }
     ZMI_HSTAMP(1);
     __syncthreads();
@@ -338,7 +368,7 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
             u32 code = 0;
             if (nb) { code = L.valPerRank[nb] + pre; for (u32 w = 0; w < wave; w++) code += L.rankCnt[nb][w]; }
             T->nbBits[tid] = (u8)nb; T->code[tid] = (u16)code;
-            if (tid < maxSV) L.weights[tid] = nb ? (u8)(huffLog + 1 - nb) : 0;             // HUF_writeCTable_wksp's bitsToWeight
+            if (tid < maxSV) { const u32 wt = nb ? huffLog + 1 - nb : 0; L.weights[tid] = (u8)wt; atomicAdd(&L.wcount[wt], 1u); }   // HUF_writeCTable_wksp's bitsToWeight + the weights' histogram
             // stream sizes = sum(count x nbBits) per segment (HUF_compress1X_usingCTable_internal + HUF_closeCStream)
             u32 bits = 0;
             for (u32 s = lane; s < 256; s += 64) bits += L.hist[wave][s] * L.nbBits[s];

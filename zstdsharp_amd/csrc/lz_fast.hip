@@ -48,8 +48,12 @@ static_assert((1u << kTileLog) == kTilePos && kGroups == 64, "tile geometry");
 
 struct LzLds {
     u8  in[kChunkSize + kInPad];
-    u32 table[1u << kHashLog];           // position+1 of the latest occurrence of the hash in EARLIER tiles; 0 = empty
-    u32 first[1u << kHashLog];           // first occurrence of the hash inside the CURRENT tile: ((15-tile) << 12) | index
+    // 64 KiB of hash tables, laid out per finder (see lz_kernel):
+    //   fast  : table u32[8192] (position+1 of the latest occurrence in EARLIER tiles; 0 = empty)
+    //           first u32[8192] (first occurrence inside the CURRENT tile: ((15-tile) << 12) | index)
+    //   dual  : firstL u32[4096] | firstS u32[4096] (as `first`, indexed by the hash's upper 12 bits)
+    //           tableL u16[8192] | tableS u16[8192] (position+1 of the hash's first occurrence in the latest earlier tile that had it)
+    u32 tabMem[2u << kHashLog];
     u8  tileLen[kTilePos];               // match length at each position of the tile (0 = none, kLenCap = "at least")
     u16 tileOff[kTilePos];
     u16 jump[kTilePos];                  // pointer-doubling array; afterwards: full length of capped selected matches
@@ -68,6 +72,14 @@ struct LzLds {
 // hash of the 6 bytes at a position (the reference's ZSTD_hash6 needs a 64x64-bit multiply, four quarter-rate VALU
 // multiplies per lane; two 32-bit multiplies over the same six bytes mix as well for a 13-bit table)
 __device__ __forceinline__ u32 hash6(u64 w) { return ((u32)w * 2654435761u + ((u32)(w >> 32) & 0xFFFFu) * 2246822519u) >> (32 - kHashLog); }
+// long hash of the dual finder: all 8 bytes (the reference's long table is hash8, U/ZstdDoubleFast.cs:60-75)
+__device__ __forceinline__ u32 hash8(u64 w) { return ((u32)w * 2654435761u + (u32)(w >> 32) * 2246822519u) >> (32 - kHashLog); }
+// short hash of the dual finder: 5 or 4 bytes (minMatch of U/Clevels.cs:490-492 at <= 128 KiB)
+template <int BYTES> __device__ __forceinline__ u32 hash_short(u64 w)
+{
+    if (BYTES == 5) return ((u32)w * 2654435761u + ((u32)(w >> 32) & 0xFFu) * 2246822519u) >> (32 - kHashLog);
+    return ((u32)w * 2654435761u) >> (32 - kHashLog);
+}
 __device__ __forceinline__ u64 read_lane64(u64 v, u32 l) { return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32); }
 
 // 8 / 4 input bytes at an arbitrary LDS position, fetched as ALIGNED dwords + v_alignbyte: consecutive lanes read
@@ -116,9 +128,13 @@ __device__ __forceinline__ u32 next_match(const LzLds& L, u32 c)
     return wj * 64 + ctz64(L.matchMask[wj]);
 }
 
-__global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ src, u64 srcSize,
-                                                       Seq* __restrict__ seqs, u8* __restrict__ lits,
-                                                       ChunkMeta* __restrict__ meta)
+// MODE 0 = fast (one 6-byte hash, levels 1-2); 1 = dual (8-byte + SHORT-byte hashes, four candidates per position,
+// levels 3-5: the place of U/ZstdDoubleFast.cs:51-247 and of the greedy row-hash search U/ZstdLazy.cs:1101-1309);
+// 2 = dual + one-step lazy deferral (levels >= 6: U/ZstdLazy.cs:1836-1905)
+template <int MODE, int SHORT>
+__global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
+                                                  Seq* __restrict__ seqs, u8* __restrict__ lits,
+                                                  ChunkMeta* __restrict__ meta)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -141,7 +157,16 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
         for (u32 i = tid; i < n; i += kTile) L.in[i] = in[i];
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
-    for (u32 i = tid; i < (1u << kHashLog); i += kTile) { L.table[i] = 0; L.first[i] = 0xFFFFFFFFu; }
+    u32* const table = L.tabMem;                           // fast
+    u32* const first = L.tabMem + (1u << kHashLog);
+    u32* const firstL = L.tabMem;                          // dual
+    u32* const firstS = L.tabMem + (1u << (kHashLog - 1));
+    u16* const tableL = reinterpret_cast<u16*>(L.tabMem + (1u << kHashLog));
+    u16* const tableS = tableL + (1u << kHashLog);
+    for (u32 i = tid; i < (1u << kHashLog); i += kTile) {
+        if (MODE == 0) { table[i] = 0; first[i] = 0xFFFFFFFFu; }
+        else           { L.tabMem[i] = 0xFFFFFFFFu; L.tabMem[(1u << kHashLog) + i] = 0; }
+    }
     if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }
     __syncthreads();
     ZMI_STAMP(0);
@@ -192,12 +217,21 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         // ---------------- probe ----------------
+        // fast: h = hash6, cand = table entry.  dual: h = hL | hS << 16, cand = tableL entry | tableS entry << 16
         u64 w[kPPT]; u32 h[kPPT], cand[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = j * kTile + tid, p = tileStart + q;
             valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cand[j] = 0;
-            if (valid[j]) { w[j] = lds_load8(L.in, p); h[j] = hash6(w[j]); cand[j] = L.table[h[j]]; atomicMin(&L.first[h[j]], stamp | q); }
+            if (valid[j]) {
+                w[j] = lds_load8(L.in, p);
+                if (MODE == 0) { h[j] = hash6(w[j]); cand[j] = table[h[j]]; atomicMin(&first[h[j]], stamp | q); }
+                else {
+                    const u32 hL = hash8(w[j]), hS = hash_short<SHORT>(w[j]);
+                    h[j] = hL | (hS << 16); cand[j] = (u32)tableL[hL] | ((u32)tableS[hS] << 16);
+                    atomicMin(&firstL[hL >> 1], stamp | q); atomicMin(&firstS[hS >> 1], stamp | q);
+                }
+            }
         }
         ZMI_STAMP(1);
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
@@ -207,7 +241,7 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
             const u32 q = j * kTile + tid, p = tileStart + q;
             u32 len = 0, off = 0;
             if (valid[j]) {
-                atomicMax(&L.table[h[j]], p + 1);
+                if (MODE == 0) atomicMax(&table[h[j]], p + 1);
                 // (1) periods 1..4: bytes p..p+7 repeat with period d and the d bytes before p agree — runs and tiny
                 //     patterns, which neither table can see inside one tile
                 u32 per = 0;
@@ -223,19 +257,70 @@ __global__ __launch_bounds__(1024) void lz_fast_kernel(const u8* __restrict__ sr
                         if (i1 && (prev4 >> 24) == ((u32)ww & 0xFFu)) per = 1;
                     }
                 }
-                if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
-                else {
-                    // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
-                    const u32 f = L.first[h[j]];
-                    if ((f >> kTileLog) == (stamp >> kTileLog) && (f & (kTilePos - 1)) < q) {
-                        const u32 cpos = tileStart + (f & (kTilePos - 1));
-                        len = match_len(L, p, cpos, w[j], n); off = p - cpos;
+                if (MODE == 0) {
+                    if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
+                    else {
+                        // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
+                        const u32 f = first[h[j]];
+                        if ((f >> kTileLog) == (stamp >> kTileLog) && (f & (kTilePos - 1)) < q) {
+                            const u32 cpos = tileStart + (f & (kTilePos - 1));
+                            len = match_len(L, p, cpos, w[j], n); off = p - cpos;
+                        }
+                        if (cand[j] && len < kLenCap) {
+                            const u32 cpos = cand[j] - 1;
+                            const u32 l2 = match_len(L, p, cpos, w[j], n);
+                            if (l2 > len) { len = l2; off = p - cpos; }
+                        }
                     }
-                    if (cand[j] && len < kLenCap) {
-                        const u32 cpos = cand[j] - 1;
-                        const u32 l2 = match_len(L, p, cpos, w[j], n);
-                        if (l2 > len) { len = l2; off = p - cpos; }
+                } else {
+                    const u32 hL = h[j] & 0xFFFFu, hS = h[j] >> 16;
+                    const u32 fL = firstL[hL >> 1], fS = firstS[hS >> 1];
+                    // the first position of a bucket in this tile becomes the bucket's entry for later tiles: one writer per
+                    // entry, no atomic (two positions with the same 13-bit hash share the 12-bit bucket)
+                    if (fL == (stamp | q)) tableL[hL] = (u16)(p + 1);
+                    if (fS == (stamp | q)) tableS[hS] = (u16)(p + 1);
+                    if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
+                    // candidates, longest wins, nearer on ties: in-tile long, earlier-tile long, in-tile short, earlier-tile short
+                    u32 c0p = 0xFFFFFFFFu, c1p = 0xFFFFFFFFu;
+                    if (len < kLenCap && (fL & (kTilePos - 1)) < q) {
+                        c0p = tileStart + (fL & (kTilePos - 1));
+                        const u32 l2 = match_len(L, p, c0p, w[j], n);
+                        if (l2 > len || (l2 == len && l2 && p - c0p < off)) { len = l2; off = p - c0p; }
                     }
+                    if (len < kLenCap && (cand[j] & 0xFFFFu)) {
+                        c1p = (cand[j] & 0xFFFFu) - 1;
+                        const u32 l2 = match_len(L, p, c1p, w[j], n);
+                        if (l2 > len) { len = l2; off = p - c1p; }
+                    }
+                    if (len < kLenCap && (fS & (kTilePos - 1)) < q) {
+                        const u32 cp = tileStart + (fS & (kTilePos - 1));
+                        if (cp != c0p) {
+                            const u32 l2 = match_len(L, p, cp, w[j], n);
+                            if (l2 > len || (l2 == len && l2 && p - cp < off)) { len = l2; off = p - cp; }
+                        }
+                    }
+                    if (len < kLenCap && (cand[j] >> 16)) {
+                        const u32 cp = (cand[j] >> 16) - 1;
+                        if (cp != c1p) {
+                            const u32 l2 = match_len(L, p, cp, w[j], n);
+                            if (l2 > len) { len = l2; off = p - cp; }
+                        }
+                    }
+                }
+            }
+            if (MODE != 0 && SHORT == 4) {
+                // a 4-byte match far away costs more than its literals (offset bits + three codes against ~5 bits a byte)
+                if (len == 4 && off >= 256) len = 0;
+            }
+            if (MODE == 2) {
+                // lazy deferral (U/ZstdLazy.cs:1836-1870): a match yields to the one starting one byte later when that one
+                // gains more (4 bits per byte saved, minus log2 of the offset, plus 4 for the literal it costs).  The next
+                // position lives in the next lane; the last lane of a wave keeps its match.
+                const u32 nLen = __shfl_down(len, 1), nOff = __shfl_down(off, 1);
+                if (len && len < kLenCap && lane < 63 && nLen) {
+                    const int g1 = (int)(len * 4) - (int)highbit32(off + 1) + 4;
+                    const int g2 = (int)(nLen * 4) - (int)highbit32(nOff + 1);
+                    if (g2 > g1) len = 0;
                 }
             }
             L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off;
@@ -424,14 +509,26 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 }
 #endif
 
-void launch_lz_fast(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
+template <int MODE, int SHORT>
+static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
 {
     static bool attrSet = false;
     if (!attrSet) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_fast_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet = true;
     }
-    hipLaunchKernelGGL(lz_fast_kernel, dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta);
+}
+
+// finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
+// minMatch at levels 4+, was measured and lost ratio on every corpus tried: far 4-byte matches cost more than literals.)
+void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
+{
+    switch (finder) {
+    case 0:  launch_one<0, 5>(src, srcSize, nChunks, seqs, lits, meta, stream); break;
+    case 1:  launch_one<1, 5>(src, srcSize, nChunks, seqs, lits, meta, stream); break;
+    default: launch_one<2, 5>(src, srcSize, nChunks, seqs, lits, meta, stream); break;
+    }
 }
 
 } // namespace zmi

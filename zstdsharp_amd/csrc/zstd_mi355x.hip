@@ -14,7 +14,7 @@
 
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
-void launch_lz_fast(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream);
+void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u32 nChunks, hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream);
@@ -141,7 +141,11 @@ static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
 }
 
 // strategy the entropy stage should assume for a level (U/Clevels.cs rows for <= 128 KiB inputs)
-static u32 strategy_for_level(int level) { (void)level; return 1; /* ZSTD_fast: the only match finder of this round */ }
+// (the encoding-type choice of ZSTD_selectEncodingType is the < ZSTD_lazy heuristic for every level: U/ZstdCompressSequences.cs:400-469)
+static u32 strategy_for_level(int level) { (void)level; return 1; }
+// match finder per level, following the strategy column of U/Clevels.cs:488-495 (<= 128 KiB rows): levels <= 2 fast,
+// 3-4 doubleFast -> the dual-hash finder, >= 5 greedy/lazy -> dual-hash + lazy deferral.  See lz_fast.hip.
+static u32 finder_for_level(int level) { return level <= 2 ? 0u : level <= 4 ? 1u : 2u; }
 
 // the compress pipeline over device-resident buffers
 static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
@@ -171,7 +175,7 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         if (first) c->timer.begin(s);
-        launch_lz_fast(src, n, nChunks, seqs, lits, meta, s);                       if (first) c->timer.mark("lz_fast", s);
+        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, s);                      if (first) c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, nChunks, s);                          if (first) c->timer.mark("huf_build", s);
         launch_huf_encode(lits, meta, tables, slots, nChunks, s);                  if (first) c->timer.mark("huf_encode", s);
         if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, s);             if (first) c->timer.mark("xxh64", s); }
