@@ -42,6 +42,34 @@ def make_zipf(n, seed, device):
     return out
 
 
+STAGE_KERNEL = {"compress/lz_fast": "lz_kernel", "compress/huf_build": "huf_build_kernel", "compress/huf_encode": "huf_encode_kernel",
+                "compress/seq_encode": "seq_encode_kernel", "compress/gather": "gather_kernel",
+                "decompress/decode_literals": "decode_literals_kernel", "decompress/decode_sequences": "decode_sequences_kernel"}
+
+
+def pmc_traffic(stage, size_mib, kind, level):
+    """HBM bytes per launch of the stage's kernel from the newest committed rocprofv3 PMC summary (tools/profile_round.sh:
+    FETCH_SIZE and WRITE_SIZE in separate passes, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    Only valid for the workload the summary was taken on; otherwise null."""
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))
+    if not files or stage not in STAGE_KERNEL:
+        return None, None
+    try:
+        d = json.load(open(files[-1]))
+        w = d["bench_line_under_profiler"]["config"]["workload"]
+        if not (w.startswith(f"{size_mib} MiB") and ("Zipf" in w) == (kind == "zipf") and f"level {level}" in w):
+            return None, None
+        for k, v in d["kernels"].items():
+            if k.startswith(STAGE_KERNEL[stage]) and v.get("fetch_corrected") is not None and v.get("write") is not None:
+                if STAGE_KERNEL[stage] == "lz_kernel" and not k.startswith("lz_kernel<" + ("0" if level <= 2 else "1" if level <= 4 else "2")):
+                    continue
+                return round((v["fetch_corrected"] + v["write"]) / 1e9, 4), os.path.basename(files[-1])
+    except Exception:
+        pass
+    return None, None
+
+
 def stage_times(lib, ctx, getter):
     ms = (ctypes.c_float * 16)(); names = (ctypes.c_char_p * 16)()
     n = getter(ctx, ms, names, 16)
@@ -166,6 +194,7 @@ def main():
         dom = max(allk, key=allk.get)
         alg_bytes = (1.0 + ratio) * n                  # (1 + r) bytes per input byte, both directions
         achieved = alg_bytes / (allk[dom] * 1e-3) / 1e9
+        traffic, traffic_src = pmc_traffic(dom, args.size_mib, args.input, args.level)
         line = {
             "metric": f"MB/s compress+decompress, level {args.level}", "value": round(world * n / (elapsed / K) / 1e6, 1) if ok else None, "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
@@ -177,7 +206,8 @@ def main():
             "compress_MBps_per_gpu": round(n / (t_comp * 1e-3) / 1e6, 1), "decompress_MBps_per_gpu": round(n / (t_dec * 1e-3) / 1e6, 1),
             "stage_ms": {k: round(v, 4) for k, v in allk.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None,
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic, "traffic_unit": "GB per launch (PMC)", "traffic_source": traffic_src,
+                         "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4),
                          "hbm_read_frac": round(n / (allk[dom] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 5)},
         }
         if world == 1 and not args.no_cpu_baseline:

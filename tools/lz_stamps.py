@@ -9,7 +9,7 @@ lib = ffi.load()
 raw = ctypes.CDLL(ffi.LIB_PATH); raw.ZSTDMI_debugReadLzStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 raw.ZSTDMI_debugReadHufStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
-names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "select+emit", "barrier C", "literals"]
+names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense:init+rounds", "dense:finish+rank"]
 n = 256 << 20
 for kind in ("zipf", "text"):
     host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), 8)[:n]
@@ -21,7 +21,7 @@ for kind in ("zipf", "text"):
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     raw.ZSTDMI_debugReadLzStamps(buf, 1)
     tot = sum(buf[i] for i in range(8)); chunks = n // 65536
-    print(kind, "lz cycles/chunk", tot // chunks, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)
+    print(kind, "lz cycles/chunk", tot // chunks, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(10)}, flush=True)
     raw.ZSTDMI_debugReadHufStamps(buf, 1)
     tot = sum(buf[i] for i in range(8))
     print(kind, "huf_build cycles/chunk", tot // chunks, {hnames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)

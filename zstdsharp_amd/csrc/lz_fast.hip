@@ -44,6 +44,7 @@ constexpr u32 kGroups   = kTilePos / 64; // 64-position groups per tile
 constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; capped matches are finished by wave 0
 constexpr u32 kInPad    = 64;
 constexpr u32 kExit     = 0xFFFFu;       // jump target "leaves the tile"
+constexpr u32 kHop      = 4;             // orbit rounds compose the jump function kHop-fold
 static_assert((1u << kTileLog) == kTilePos && kGroups == 64, "tile geometry");
 
 struct LzLds {
@@ -62,7 +63,8 @@ struct LzLds {
     u64 selMask[kGroups];                // bit = match is on the greedy orbit (selected)
     u64 covMask[kGroups];                // bit = byte covered by a selected match (tile-local)
     u32 wordRank[kGroups + 1];           // selected matches before each group
-    u32 endOf[kTilePos / 4 + 2];         // endOf[r+1] = absolute end of the r-th selected match of the tile; endOf[0] = anchor
+    u16 jumpB[kTilePos];                 // second buffer of the doubling rounds; once they end it is reused as
+                                         // endOf[r+1] = absolute end of the r-th selected match of the tile (u32[kTilePos/4+2]), endOf[0] = anchor
     u32 waveCnt[2][16];
     u64 nzWords;                         // bit g = matchMask[g] != 0 (accumulated with atomicOr during the probe, reset per tile)
     u32 matchCount;                      // matches in the current tile (decides sparse / dense selection)
@@ -71,14 +73,28 @@ struct LzLds {
 
 // hash of the 6 bytes at a position (the reference's ZSTD_hash6 needs a 64x64-bit multiply, four quarter-rate VALU
 // multiplies per lane; two 32-bit multiplies over the same six bytes mix as well for a 13-bit table)
-__device__ __forceinline__ u32 hash6(u64 w) { return ((u32)w * 2654435761u + ((u32)(w >> 32) & 0xFFFFu) * 2246822519u) >> (32 - kHashLog); }
-// long hash of the dual finder: all 8 bytes (the reference's long table is hash8, U/ZstdDoubleFast.cs:60-75)
-__device__ __forceinline__ u32 hash8(u64 w) { return ((u32)w * 2654435761u + (u32)(w >> 32) * 2246822519u) >> (32 - kHashLog); }
-// short hash of the dual finder: 5 or 4 bytes (minMatch of U/Clevels.cs:490-492 at <= 128 KiB)
-template <int BYTES> __device__ __forceinline__ u32 hash_short(u64 w)
+// (v_mul_u32_u24 is a full-rate instruction, the 32-bit multiply is not: three input bytes per multiply)
+__device__ __forceinline__ u32 hash6p(u64 w)
 {
-    if (BYTES == 5) return ((u32)w * 2654435761u + ((u32)(w >> 32) & 0xFFu) * 2246822519u) >> (32 - kHashLog);
-    return ((u32)w * 2654435761u) >> (32 - kHashLog);
+    const u32 lo = (u32)w, hi = (u32)(w >> 32);
+    return __umul24(lo & 0xFFFFFFu, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbyte(hi, lo, 3) & 0xFFFFFFu, 0x85EBCBu);
+}
+// a hash product gives the table index (top kHashLog bits) and a 16-bit tag (the bits below): entries carry the tag in
+// their low half, so a candidate whose tag differs is dropped without touching the input bytes
+__device__ __forceinline__ u32 hidx(u32 prod) { return prod >> (32 - kHashLog); }
+__device__ __forceinline__ u32 htag(u32 prod) { return (prod >> (16 - kHashLog)) & 0xFFFFu; }
+// long hash of the dual finder: all 8 bytes (the reference's long table is hash8, U/ZstdDoubleFast.cs:60-75)
+__device__ __forceinline__ u32 hash8p(u64 w)
+{
+    const u32 lo = (u32)w, hi = (u32)(w >> 32);
+    return __umul24(lo & 0xFFFFFFu, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbyte(hi, lo, 3) & 0xFFFFFFu, 0x85EBCBu) + __umul24(hi >> 16, 0xC2B2AFu);
+}
+// short hash of the dual finder: 5 or 4 bytes (minMatch of U/Clevels.cs:490-492 at <= 128 KiB)
+template <int BYTES> __device__ __forceinline__ u32 hash_shortp(u64 w)
+{
+    const u32 lo = (u32)w, hi = (u32)(w >> 32);
+    if (BYTES == 5) return __umul24(lo & 0xFFFFFFu, 0x9E3779u) + __umul24(__builtin_amdgcn_alignbyte(hi, lo, 3) & 0xFFFFu, 0x85EBCBu);
+    return lo * 2654435761u;
 }
 __device__ __forceinline__ u64 read_lane64(u64 v, u32 l) { return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32); }
 
@@ -157,6 +173,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         for (u32 i = tid; i < n; i += kTile) L.in[i] = in[i];
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
+    u32* const endOf = reinterpret_cast<u32*>(L.jumpB);
     u32* const table = L.tabMem;                           // fast
     u32* const first = L.tabMem + (1u << kHashLog);
     u32* const firstL = L.tabMem;                          // dual
@@ -181,7 +198,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     auto emit_match = [&](u32 tileStart, u32 q, u32 rank, u32 end) {
         u32 p = tileStart + q;
         const u32 off = L.tileOff[q];
-        const u32 litStart = L.endOf[rank];
+        const u32 litStart = endOf[rank];
         const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
         // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
         while (p > floorPos && p > off && L.in[p - 1] == L.in[p - off - 1]) --p;
@@ -217,19 +234,22 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         // ---------------- probe ----------------
-        // fast: h = hash6, cand = table entry.  dual: h = hL | hS << 16, cand = tableL entry | tableS entry << 16
-        u64 w[kPPT]; u32 h[kPPT], cand[kPPT]; bool valid[kPPT];
+        // fast: h = hash product, cand = table entry.  dual: h = long product, h2 = short product, cand = tableL | tableS << 16
+        u64 w[kPPT]; u32 h[kPPT], h2[kPPT], cand[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = j * kTile + tid, p = tileStart + q;
-            valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cand[j] = 0;
+            valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
             if (valid[j]) {
                 w[j] = lds_load8(L.in, p);
-                if (MODE == 0) { h[j] = hash6(w[j]); cand[j] = table[h[j]]; atomicMin(&first[h[j]], stamp | q); }
-                else {
-                    const u32 hL = hash8(w[j]), hS = hash_short<SHORT>(w[j]);
-                    h[j] = hL | (hS << 16); cand[j] = (u32)tableL[hL] | ((u32)tableS[hS] << 16);
-                    atomicMin(&firstL[hL >> 1], stamp | q); atomicMin(&firstS[hS >> 1], stamp | q);
+                if (MODE == 0) {
+                    h[j] = hash6p(w[j]);
+                    cand[j] = table[hidx(h[j])]; atomicMin(&first[hidx(h[j])], ((stamp | q) << 16) | htag(h[j]));
+                } else {
+                    h[j] = hash8p(w[j]); h2[j] = hash_shortp<SHORT>(w[j]);
+                    const u32 hL = hidx(h[j]), hS = hidx(h2[j]);
+                    cand[j] = (u32)tableL[hL] | ((u32)tableS[hS] << 16);
+                    atomicMin(&firstL[hL >> 1], ((stamp | q) << 16) | htag(h[j])); atomicMin(&firstS[hS >> 1], ((stamp | q) << 16) | htag(h2[j]));
                 }
             }
         }
@@ -241,40 +261,44 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             const u32 q = j * kTile + tid, p = tileStart + q;
             u32 len = 0, off = 0;
             if (valid[j]) {
-                if (MODE == 0) atomicMax(&table[h[j]], p + 1);
+                if (MODE == 0) atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | htag(h[j]));
                 // (1) periods 1..4: bytes p..p+7 repeat with period d and the d bytes before p agree — runs and tiny
                 //     patterns, which neither table can see inside one tile
                 u32 per = 0;
                 {
-                    const u64 ww = w[j];
-                    const bool i1 = ((ww ^ (ww >> 8)) << 8) == 0, i2 = ((ww ^ (ww >> 16)) << 16) == 0,
-                               i3 = ((ww ^ (ww >> 24)) << 24) == 0, i4 = ((ww ^ (ww >> 32)) << 32) == 0;
-                    if ((i1 | i2 | i3 | i4) && p >= 4) {           // rare outside runs: only then look at the bytes before p
+                    // prefilter with two 32-bit tests: period 4 over the 8 bytes (implied by periods 1 and 2) or period 3
+                    const u32 lo = (u32)w[j], hi = (u32)(w[j] >> 32);
+                    const bool i4 = lo == hi;
+                    const bool i3 = __builtin_amdgcn_alignbyte(hi, lo, 3) == lo && ((hi ^ (hi >> 24)) & 0xFFu) == 0;
+                    if ((i4 | i3) && p >= 4) {                     // rare outside runs: only then look at the bytes before p
                         const u32 prev4 = lds_load4(L.in, p - 4);
-                        if (i4 && prev4 == (u32)ww) per = 4;
-                        if (i3 && (prev4 >> 8) == ((u32)ww & 0xFFFFFFu)) per = 3;
-                        if (i2 && (prev4 >> 16) == ((u32)ww & 0xFFFFu)) per = 2;
-                        if (i1 && (prev4 >> 24) == ((u32)ww & 0xFFu)) per = 1;
+                        const bool i2 = i4 && ((lo ^ (lo >> 16)) & 0xFFFFu) == 0, i1 = i2 && ((lo ^ (lo >> 8)) & 0xFFu) == 0;
+                        if (i4 && prev4 == lo) per = 4;
+                        if (i3 && (prev4 >> 8) == (lo & 0xFFFFFFu)) per = 3;
+                        if (i2 && (prev4 >> 16) == (lo & 0xFFFFu)) per = 2;
+                        if (i1 && (prev4 >> 24) == (lo & 0xFFu)) per = 1;
                     }
                 }
                 if (MODE == 0) {
                     if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
                     else {
                         // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
-                        const u32 f = first[h[j]];
-                        if ((f >> kTileLog) == (stamp >> kTileLog) && (f & (kTilePos - 1)) < q) {
-                            const u32 cpos = tileStart + (f & (kTilePos - 1));
+                        const u32 f = first[hidx(h[j])], tag = htag(h[j]);
+                        const u32 fq = (f >> 16) & (kTilePos - 1);
+                        if (fq < q && (f & 0xFFFFu) == tag) {
+                            const u32 cpos = tileStart + fq;
                             len = match_len(L, p, cpos, w[j], n); off = p - cpos;
                         }
-                        if (cand[j] && len < kLenCap) {
-                            const u32 cpos = cand[j] - 1;
+                        if (cand[j] && (cand[j] & 0xFFFFu) == tag && len < kLenCap) {
+                            const u32 cpos = (cand[j] >> 16) - 1;
                             const u32 l2 = match_len(L, p, cpos, w[j], n);
                             if (l2 > len) { len = l2; off = p - cpos; }
                         }
                     }
                 } else {
-                    const u32 hL = h[j] & 0xFFFFu, hS = h[j] >> 16;
-                    const u32 fL = firstL[hL >> 1], fS = firstS[hS >> 1];
+                    const u32 hL = hidx(h[j]), hS = hidx(h2[j]);
+                    const u32 eL = firstL[hL >> 1], eS = firstS[hS >> 1];
+                    const u32 fL = eL >> 16, fS = eS >> 16;
                     // the first position of a bucket in this tile becomes the bucket's entry for later tiles: one writer per
                     // entry, no atomic (two positions with the same 13-bit hash share the 12-bit bucket)
                     if (fL == (stamp | q)) tableL[hL] = (u16)(p + 1);
@@ -282,7 +306,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
                     // candidates, longest wins, nearer on ties: in-tile long, earlier-tile long, in-tile short, earlier-tile short
                     u32 c0p = 0xFFFFFFFFu, c1p = 0xFFFFFFFFu;
-                    if (len < kLenCap && (fL & (kTilePos - 1)) < q) {
+                    if (len < kLenCap && (fL & (kTilePos - 1)) < q && (eL & 0xFFFFu) == htag(h[j])) {
                         c0p = tileStart + (fL & (kTilePos - 1));
                         const u32 l2 = match_len(L, p, c0p, w[j], n);
                         if (l2 > len || (l2 == len && l2 && p - c0p < off)) { len = l2; off = p - c0p; }
@@ -292,7 +316,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                         const u32 l2 = match_len(L, p, c1p, w[j], n);
                         if (l2 > len) { len = l2; off = p - c1p; }
                     }
-                    if (len < kLenCap && (fS & (kTilePos - 1)) < q) {
+                    if (len < kLenCap && (fS & (kTilePos - 1)) < q && (eS & 0xFFFFu) == htag(h2[j])) {
                         const u32 cp = tileStart + (fS & (kTilePos - 1));
                         if (cp != c0p) {
                             const u32 l2 = match_len(L, p, cp, w[j], n);
@@ -323,7 +347,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (g2 > g1) len = 0;
                 }
             }
-            L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off;
+            if (len) { L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off; }      // only read where matchMask has the bit
             const u64 mm = ballot(len != 0), cm = ballot(len == kLenCap);
             if (lane == 0) {
                 const u32 g = j * 16 + wave;
@@ -340,38 +364,42 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const bool dense = any && matchCount > 64;
         if (dense) {
             // ---------------- select: orbit of the greedy parse by pointer doubling ----------------
+            u16* cur = L.jump; u16* nxt = L.jumpB;
+            bool has[kPPT];
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) {
                 const u32 q = j * kTile + tid;
-                const u32 len = L.tileLen[q];
-                if (len) L.jump[q] = (u16)next_match(L, q + len);
+                has[j] = (L.matchMask[q >> 6] >> (q & 63)) & 1ull;
+                if (has[j]) cur[q] = (u16)next_match(L, q + L.tileLen[q]);
             }
-            if (tid == 0) { const u32 s0 = next_match(L, c0); if (s0 != kExit) L.selMask[s0 >> 6] = 1ull << (s0 & 63); }
+            const u32 s0 = next_match(L, c0);                       // uniform: first match at or after the entry cursor
+            if (tid == 0 && s0 != kExit) L.selMask[s0 >> 6] = 1ull << (s0 & 63);
             __syncthreads();
-            for (u32 round = 0; round < kTileLog; ++round) {
-                u32 nv[kPPT]; u32 added = 0;
+            // Each round replaces J by J^4 (double-buffered, one barrier) and lets every selected position mark J, J^2, J^3
+            // of itself: after r rounds the orbit points of index < 4^r are marked, and J^(4^r)(s0) leaving the tile ends it.
+            if (s0 != kExit) {
+                for (u32 round = 0; round < kTileLog; ++round) {
 #pragma unroll
-                for (u32 j = 0; j < kPPT; ++j) {
-                    const u32 q = j * kTile + tid;
-                    nv[j] = kExit;
-                    if (L.tileLen[q]) {
-                        const u32 jq = L.jump[q];
-                        if (jq != kExit) {
-                            if ((L.selMask[q >> 6] >> (q & 63)) & 1ull) {
-                                const u64 bit = 1ull << (jq & 63);
-                                const u64 old = atomicOr((unsigned long long*)&L.selMask[jq >> 6], (unsigned long long)bit);
-                                added |= !(old & bit);
+                    for (u32 j = 0; j < kPPT; ++j) {
+                        const u32 q = j * kTile + tid;
+                        if (has[j]) {
+                            const bool isSel = (L.selMask[q >> 6] >> (q & 63)) & 1ull;
+                            u32 a = cur[q];
+#pragma unroll
+                            for (u32 hop = 1; hop < kHop; ++hop) {
+                                if (a == kExit) break;
+                                if (isSel) atomicOr((unsigned long long*)&L.selMask[a >> 6], (unsigned long long)(1ull << (a & 63)));
+                                a = cur[a];
                             }
-                            nv[j] = L.jump[jq];
+                            nxt[q] = (u16)a;
                         }
                     }
+                    __syncthreads();
+                    { u16* t_ = cur; cur = nxt; nxt = t_; }
+                    if (cur[s0] == kExit) break;
                 }
-                const int grew = __syncthreads_or((int)added);    // all reads of jump[] done; did the orbit grow?
-#pragma unroll
-                for (u32 j = 0; j < kPPT; ++j) { const u32 q = j * kTile + tid; if (L.tileLen[q]) L.jump[q] = (u16)nv[j]; }
-                __syncthreads();
-                if (!grew) break;
             }
+            ZMI_STAMP(8);
             if (wave == 0) {
                 // ---- finish capped matches in order; drop the selections they swallow ----
                 u32 from = 0;                  // consider selected capped matches at tile positions >= from
@@ -403,9 +431,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 const u32 incl = wave_scan_incl(cnt);
                 L.wordRank[lane] = incl - cnt;
                 if (lane == 63) L.wordRank[64] = incl;
-                if (lane == 0) L.endOf[0] = cursor;
+                if (lane == 0) endOf[0] = cursor;
             }
             __syncthreads();
+            ZMI_STAMP(9);
             u32 myRank[kPPT], myEnd[kPPT]; bool sel[kPPT];
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) {
@@ -417,7 +446,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     myRank[j] = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
                     const u32 len = L.tileLen[q];
                     myEnd[j] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
-                    L.endOf[myRank[j] + 1] = myEnd[j];
+                    endOf[myRank[j] + 1] = myEnd[j];
                 }
             }
             __syncthreads();
@@ -450,8 +479,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 const bool sel = (selBits >> lane) & 1ull;
                 const u32 rank = popc64(selBits & lanemask_lt());
                 const u32 nSel = popc64(selBits);
-                if (lane == 0) { L.endOf[0] = cursor; L.wordRank[64] = nSel; }
-                if (sel) L.endOf[rank + 1] = myEnd;
+                if (lane == 0) { endOf[0] = cursor; L.wordRank[64] = nSel; }
+                if (sel) endOf[rank + 1] = myEnd;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                 if (sel) emit_match(tileStart, q, rank, myEnd);
             }
@@ -462,24 +491,27 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 nSel = L.wordRank[64];
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
         {
-            const u32 q4 = tid * 4;                // 1024 threads cover the tile, 4 positions each
+            // Every wave scans the 64 group words itself (one LDS read per lane), so the compaction offsets need neither a
+            // cross-wave table nor another barrier.  keepG(g) = bytes of group g that are literals of this tile.
+            auto keepG = [&](u32 g) -> u64 {
+                const u32 g0 = g * 64;
+                u64 k = ~L.covMask[g];
+                const u32 pG = tileStart + g0;
+                if (pG >= n) k = 0; else if (n - pG < 64) k &= (1ull << (n - pG)) - 1;
+                if (c0 > g0) k = (c0 - g0 >= 64) ? 0ull : (k & (~0ull << (c0 - g0)));      // before the entry cursor: inside an earlier match
+                return k;
+            };
+            const u32 gcnt = popc64(keepG(lane));
+            const u32 gincl = wave_scan_incl(gcnt);
+            const u32 total = read_lane(gincl, 63);
+            const u32 q4 = tid * 4, myG = q4 >> 6;           // 1024 threads cover the tile, 4 positions each
             const u32 p = tileStart + q4;
-            u32 keep = 0;
-            if (p < n) {
-                keep = ~(u32)(L.covMask[q4 >> 6] >> (q4 & 63)) & 0xFu;
-                if (n - p < 4) keep &= (1u << (n - p)) - 1;
-                if (c0 > q4) keep &= (c0 - q4 >= 4) ? 0u : (0xFu << (c0 - q4));      // before the entry cursor: inside an earlier match
-            }
-            const u32 cnt = __builtin_popcount(keep);
-            const u32 incl = wave_scan_incl(cnt);
-            if (lane == 63) L.waveCnt[t & 1][wave] = incl;
-            const u32 lastEnd = nSel ? L.endOf[nSel] : cursor;
-            __syncthreads();
-            u32 before = 0, total = 0;
-#pragma unroll
-            for (u32 k = 0; k < 16; ++k) { const u32 v = L.waveCnt[t & 1][k]; total += v; if (k < wave) before += v; }
+            const u64 kg = keepG(myG);
+            const u32 gexcl = __shfl(gincl - gcnt, (int)myG);
+            const u32 keep = (u32)(kg >> (q4 & 63)) & 0xFu;
+            const u32 lastEnd = nSel ? endOf[nSel] : cursor;
             if (keep) {
-                u8* o = litOut + litBase + before + incl - cnt;
+                u8* o = litOut + litBase + gexcl + popc64(kg & ((1ull << (q4 & 63)) - 1));
                 const u32 v = *reinterpret_cast<const u32*>(L.in + p);
                 if (keep == 0xFu) *(u32u*)o = v;
                 else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
