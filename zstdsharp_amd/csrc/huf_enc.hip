@@ -28,23 +28,34 @@ __device__ unsigned long long g_hufStamps[16];
 
 struct Node { u32 count; u16 parent; u8 byte; u8 nbBits; };
 
+// hand-off from huf_hist_kernel to huf_tree_kernel, kept in the chunk's output slot (overwritten later by huf_encode)
+struct HufWork {
+    u32 leafCount[256];         // HUF_sort's result: counts in descending order ...
+    u8  leafByte[256];          // ... and their symbols
+    u16 hist[4][256];           // per-stream histograms
+    u32 flags[4];               // compressible?, maxSymbolValue, RLE?, RLE byte
+};
+static_assert(sizeof(HufWork) <= kSlotStride, "hand-off fits the slot");
+
+struct HufTreeLds {
+    Node nodes[513];
+    u8  nbBits[256];
+    u8  weights[256];
+    u32 wcount[13]; s16 wnorm[13]; u16 wstate[64]; SymTT wtt[13]; u16 wcumul[15]; u8 wsym[64];
+    u32 valPerRank[13];
+    u32 sh[8];
+};
+
 struct HufBuildLds {
-    u32 hist[4][256];
+    u32 hist[4][2][256];
     u32 sample[2][256];
     u32 count[256];
     Node nodes[513];
     u16 rankBase[192], rankCurr[192];
-    u8  nbBits[256];
-    u8  weights[256];
-    // FSE scratch for the weights (alphabet 0..12, tableLog <= 6)
-    u32 wcount[13]; s16 wnorm[13]; u16 wstate[64]; SymTT wtt[13]; u16 wcumul[15]; u8 wsym[64];
     u32 sampleMax[2];
     u32 redMaxSV[4], redLargest[4];
     u8  sortIdx[256];
-    int qsStack[26][64];        // one explicit quicksort stack per log2 bucket (buckets are sorted by separate lanes)
-    u32 rankCnt[13][4];
-    u32 valPerRank[13];
-    u32 streamBits[4];
+    s16 qsStack[26][64];        // one explicit quicksort stack per log2 bucket (buckets are sorted by separate lanes); values -1..256
     u32 sh[8];                  // decisions shared by the workgroup: see enum below
 };
 enum { kShCompressed = 0, kShMaxSV, kShRle, kShRleByte, kShHuffLog, kShNonNull, kShRoot, kShHSize };
@@ -71,21 +82,21 @@ __device__ inline int huf_partition(Node* a, int low, int high)
 // HUF_simpleQuickSort: a call checks the insertion-sort threshold once, then partitions in a loop, recursing
 // (threshold checked again) into the smaller side and continuing the loop (threshold NOT checked) on the larger.
 // Sub-ranges are disjoint, so an explicit stack of {low, high, isCall} reproduces the result exactly.
-__device__ inline void huf_quick_sort(Node* a, int low0, int high0, int* stack)
+__device__ inline void huf_quick_sort(Node* a, int low0, int high0, s16* stack)
 {
     int sp = 0;
-    stack[sp++] = low0; stack[sp++] = high0; stack[sp++] = 1;
+    stack[sp++] = (s16)low0; stack[sp++] = (s16)high0; stack[sp++] = 1;
     while (sp) {
         const int isCall = stack[--sp]; const int high = stack[--sp]; const int low = stack[--sp];
         if (isCall && high - low < 8) { huf_insertion_sort(a, low, high); continue; }
         if (!(low < high)) continue;
         const int idx = huf_partition(a, low, high);
         if (idx - low < high - idx) {
-            stack[sp++] = idx + 1; stack[sp++] = high;    stack[sp++] = 0;
-            stack[sp++] = low;     stack[sp++] = idx - 1; stack[sp++] = 1;
+            stack[sp++] = (s16)(idx + 1); stack[sp++] = (s16)high;      stack[sp++] = 0;
+            stack[sp++] = (s16)low;       stack[sp++] = (s16)(idx - 1); stack[sp++] = 1;
         } else {
-            stack[sp++] = low;     stack[sp++] = idx - 1; stack[sp++] = 0;
-            stack[sp++] = idx + 1; stack[sp++] = high;    stack[sp++] = 1;
+            stack[sp++] = (s16)low;       stack[sp++] = (s16)(idx - 1); stack[sp++] = 0;
+            stack[sp++] = (s16)(idx + 1); stack[sp++] = (s16)high;      stack[sp++] = 1;
         }
     }
 }
@@ -184,7 +195,7 @@ __device__ inline u32 huf_set_max_height(Node* huffNode, u32 lastNonNull, u32 ma
 }
 
 // ---- HUF_compressWeights (U/HufCompress.cs:40-125); returns bytes written, 0 = not compressible, 1 = single symbol ----
-__device__ inline u32 huf_compress_weights(HufBuildLds& L, u8* dst, u32 wtSize)
+__device__ inline u32 huf_compress_weights(HufTreeLds& L, u8* dst, u32 wtSize)
 {
     u32 maxSV = 12;
     if (wtSize <= 1) return 0;
@@ -222,34 +233,30 @@ __device__ inline u32 huf_compress_weights(HufBuildLds& L, u8* dst, u32 wtSize)
 
 __device__ __forceinline__ u32 min_gain(u32 srcSize) { return (srcSize >> 6) + 2; }   // ZSTD_minGain, strategies < btultra
 
-__global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ lits, ChunkMeta* __restrict__ meta,
-                                                        HufTable* __restrict__ tables)
+// Front half: everything that is parallel over the literals or over the 256 symbols.  Hands the sorted leaves, the four
+// per-stream histograms and the verdicts to huf_tree_kernel through the chunk's (still unused) output slot.
+__global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ lits, const ChunkMeta* __restrict__ meta,
+                                                       u8* __restrict__ slots)
 {
     __shared__ HufBuildLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    ChunkMeta m = meta[c];
-    const u32 litSize = m.litSize;
+    const u32 litSize = meta[c].litSize, nbSeqIn = meta[c].nbSeq;
+    HufWork* __restrict__ W = reinterpret_cast<HufWork*>(slots + (u64)c * kSlotStride);
     const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
-    const u32 lhSizeRaw = 1 + (litSize > 31) + (litSize > 4095);
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
 
     // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
-    if (litSize <= 63) {
-        if (tid == 0) { m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize; meta[c] = m; }
-        return;
-    }
-    for (u32 i = tid; i < 4 * 256; i += 256) (&L.hist[0][0])[i] = 0;
+    if (litSize <= 63) return;                 // huf_tree_kernel stores them raw
+    for (u32 i = tid; i < 8 * 256; i += 256) (&L.hist[0][0][0])[i] = 0;
     for (u32 i = tid; i < 2 * 256; i += 256) (&L.sample[0][0])[i] = 0;
     for (u32 i = tid; i < 513; i += 256) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
-    L.nbBits[tid] = 0;
-    if (tid < 13) L.wcount[tid] = 0;
     __syncthreads();
     const u32 seg = (litSize + 3) / 4;
     {   // wave w counts segment w (these are also the per-stream histograms that size the four streams)
         const u32 s0 = wave * seg, s1 = (s0 + seg < litSize) ? s0 + seg : litSize;
-        u32* H = L.hist[wave];
+        u32* H = L.hist[wave][lane & 1];      // two copies per wave, by lane parity: halves same-address atomic serialisation
         if (s0 < s1) {
             // 16 bytes per lane per load (the literal buffer is 64 KiB-aligned): a byte-per-lane loop is bound by one
             // global-load latency per 64 bytes
@@ -257,28 +264,52 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
             if (s0 + lane < a0) atomicAdd(&H[lit[s0 + lane]], 1u);
             const u32 nVec = (s1 - a0) >> 4;
             const uint4* v4 = reinterpret_cast<const uint4*>(lit + a0);
-#pragma unroll 2
+            // Skewed data serialises the atomics of the lanes that hold the most frequent byte.  Guess that byte from 64
+            // samples and count it with a ballot instead (scalar add, no LDS traffic); everything else takes the atomic.
+            u32 hot = 256, hotCnt = 0;
+            if (nVec >= 64) {
+                const u32 b0 = v4[lane].x & 0xFFu;
+                u32 best = 0;
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) {
+                    const u32 cand = read_lane(b0, k * 8);
+                    const u32 cn = popc64(ballot(b0 == cand));
+                    if (cn > best) { best = cn; hot = cand; }
+                }
+                if (best < 6) hot = 256;
+            }
             for (u32 i = lane; i < nVec; i += 64) {
                 const uint4 v = v4[i];
                 const u32 d[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
                 for (u32 k = 0; k < 4; ++k) {
-                    atomicAdd(&H[d[k] & 0xFF], 1u); atomicAdd(&H[(d[k] >> 8) & 0xFF], 1u);
-                    atomicAdd(&H[(d[k] >> 16) & 0xFF], 1u); atomicAdd(&H[d[k] >> 24], 1u);
+#pragma unroll
+                    for (u32 b = 0; b < 4; ++b) {
+                        const u32 sym = (d[k] >> (8 * b)) & 0xFFu;
+                        const bool isHot = sym == hot;
+                        hotCnt += popc64(ballot(isHot));
+                        if (!isHot) atomicAdd(&H[sym], 1u);
+                    }
                 }
             }
+            if (lane == 0 && hot < 256) atomicAdd(&H[hot], hotCnt);
             const u32 t0 = a0 + (nVec << 4);
             if (t0 + lane < s1) atomicAdd(&H[lit[t0 + lane]], 1u);
         }
     }
-    const u32 suspect = (m.nbSeq == 0) || (litSize / m.nbSeq >= 20);
+    const u32 suspect = (nbSeqIn == 0) || (litSize / nbSeqIn >= 20);
     const bool doSample = suspect && litSize >= 4096 * 10;
     if (doSample && wave < 2) {       // HUF_compress_internal's 2 x 4 KiB pre-check (U/HufCompress.cs:1412-1446)
         const u8* sp = wave == 0 ? lit : lit + litSize - 4096;
         for (u32 i = lane; i < 4096; i += 64) atomicAdd(&L.sample[wave][sp[i]], 1u);
     }
     __syncthreads();
-    L.count[tid] = L.hist[0][tid] + L.hist[1][tid] + L.hist[2][tid] + L.hist[3][tid];
+    {
+        u32 tot = 0;
+#pragma unroll
+        for (u32 w = 0; w < 4; ++w) { const u32 v = L.hist[w][0][tid] + L.hist[w][1][tid]; W->hist[w][tid] = (u16)v; tot += v; }
+        L.count[tid] = tot;
+    }
     if (doSample && wave < 2) {
         u32 mx = 0;
         for (u32 i = lane; i < 256; i += 64) { const u32 v = L.sample[wave][i]; mx = v > mx ? v : mx; }
@@ -288,9 +319,6 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     __syncthreads();
 
     ZMI_HSTAMP(0);
-    const u32 lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
-    const u32 single = litSize < 256;
-    HufTable* T = tables + c;
     {   // compressible at all?  (HUF_compress_internal, U/HufCompress.cs:1412-1462) — every thread reaches the same verdict
         const u32 cnt = L.count[tid];
         const u64 nz = ballot(cnt != 0);
@@ -325,68 +353,117 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     }
     ZMI_HSTAMP(1);
     __syncthreads();
-    const u32 maxSV = L.sh[kShMaxSV];
     if (L.sh[kShCompressed]) {
         if (tid < 26) huf_sort_bucket(L, tid);                 // HUF_sort's per-bucket quicksorts, one bucket per lane
         __syncthreads();
-        ZMI_HSTAMP(2);
-        Node* huffNode = L.nodes + 1;
-        if (tid == 0) { int root = 0; L.sh[kShNonNull] = (u32)huf_build_tree(huffNode, maxSV, &root); L.sh[kShRoot] = (u32)root; }
-        ZMI_HSTAMP(3);
-        __syncthreads();
-        {   // depth of every leaf = number of parent links up to the root (HUF_buildTree's nbBits loops)
-            const u32 nonNull = L.sh[kShNonNull], root = L.sh[kShRoot];
-            if (tid <= nonNull) { u32 node = tid, d = 0; while (node != root) { node = huffNode[node].parent; d++; } huffNode[tid].nbBits = (u8)d; }
+        W->leafCount[tid] = L.nodes[1 + tid].count; W->leafByte[tid] = L.nodes[1 + tid].byte;
+    }
+    if (tid < 4) W->flags[tid] = L.sh[tid];                    // compressed, maxSV, rle, rleByte
+    ZMI_HSTAMP(2);
+#ifdef ZMI_LZ_STAMPS
+    if (tid == 0) for (int i = 0; i < 3; i++) atomicAdd(&g_hufStamps[i], stampAcc[i]);
+#endif
+}
+
+// Back half: the serial constructions (HUF_buildTree, HUF_setMaxHeight, HUF_compressWeights) and the decisions.  One
+// wave per chunk and ~6 KiB of LDS, so that ~25 chunks per CU hide each other's LDS latency; per-symbol steps run
+// four symbols per lane.
+__global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ meta, HufTable* __restrict__ tables, const u8* __restrict__ slots)
+{
+    __shared__ HufTreeLds L;
+    const u32 c = blockIdx.x, lane = threadIdx.x, tid = lane;
+    ChunkMeta m = meta[c];
+    const u32 litSize = m.litSize;
+    const u32 lhSizeRaw = 1 + (litSize > 31) + (litSize > 4095);
+    const HufWork* __restrict__ W = reinterpret_cast<const HufWork*>(slots + (u64)c * kSlotStride);
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
+    // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
+    if (litSize <= 63) {
+        if (tid == 0) { m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize; meta[c] = m; }
+        return;
+    }
+    const u32 lhSize = 3 + (litSize >= 1024) + (litSize >= 16384);
+    const u32 single = litSize < 256;
+    HufTable* T = tables + c;
+    const u32 shCompressed = W->flags[0], maxSV = W->flags[1], shRle = W->flags[2], shRleByte = W->flags[3];
+    u32 huffLog = 0;
+    u32 streamBits[4] = { 0, 0, 0, 0 };
+    if (shCompressed) {
+        for (u32 k = 0; k < 4; ++k) {
+            const u32 pos = k * 64 + lane;
+            Node nd; nd.count = W->leafCount[pos]; nd.parent = 0; nd.byte = W->leafByte[pos]; nd.nbBits = 0;
+            L.nodes[1 + pos] = nd;
+            Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0;
+            L.nodes[257 + pos] = z;
+            L.nbBits[pos] = 0;
         }
-        __syncthreads();
+        if (lane == 0) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[0] = z; }
+        if (lane < 13) L.wcount[lane] = 0;
+        wave_lds_sync();
+        Node* huffNode = L.nodes + 1;
+        if (lane == 0) { int root = 0; L.sh[kShNonNull] = (u32)huf_build_tree(huffNode, maxSV, &root); L.sh[kShRoot] = (u32)root; }
+        wave_lds_sync();
+        ZMI_HSTAMP(3);
+        const u32 nonNull = L.sh[kShNonNull], root = L.sh[kShRoot];
+        for (u32 k = 0; k < 4; ++k) {   // depth of every leaf = number of parent links up to the root (HUF_buildTree's nbBits loops)
+            const u32 pos = k * 64 + lane;
+            if (pos <= nonNull) { u32 node = pos, d = 0; while (node != root) { node = huffNode[node].parent; d++; } huffNode[pos].nbBits = (u8)d; }
+        }
+        wave_lds_sync();
         ZMI_HSTAMP(4);
-        if (tid == 0) {
-            u32 huffLog = fse_optimal_table_log(11, litSize, maxSV, 1);
-            const u32 nonNullRank = L.sh[kShNonNull];
-            huffLog = huf_set_max_height(huffNode, nonNullRank, huffLog);
+        if (lane == 0) {
+            u32 hl = fse_optimal_table_log(11, litSize, maxSV, 1);
+            hl = huf_set_max_height(huffNode, nonNull, hl);
             u16 nbPerRank[13];
             for (int i = 0; i < 13; i++) nbPerRank[i] = 0;
-            for (u32 n = 0; n <= nonNullRank; n++) nbPerRank[huffNode[n].nbBits]++;
-            { u16 mn = 0; for (int n = (int)huffLog; n > 0; n--) { L.valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
+            for (u32 n = 0; n <= nonNull; n++) nbPerRank[huffNode[n].nbBits]++;
+            { u16 mn = 0; for (int n = (int)hl; n > 0; n--) { L.valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
             L.valPerRank[0] = 0;
-            L.sh[kShHuffLog] = huffLog;
+            L.sh[kShHuffLog] = hl;
         }
+        wave_lds_sync();
         ZMI_HSTAMP(5);
-        __syncthreads();
-        const u32 huffLog = L.sh[kShHuffLog];
-        if (tid <= maxSV) L.nbBits[huffNode[tid].byte] = huffNode[tid].nbBits;        // HUF_buildCTableFromTree
-        __syncthreads();
+        huffLog = L.sh[kShHuffLog];
+        for (u32 k = 0; k < 4; ++k) { const u32 pos = k * 64 + lane; if (pos <= maxSV) L.nbBits[huffNode[pos].byte] = huffNode[pos].nbBits; }   // HUF_buildCTableFromTree
+        wave_lds_sync();
         {   // canonical codes: symbols of one length get consecutive values in symbol order (U/HufCompress.cs:766-785)
-            const u32 nb = tid <= maxSV ? L.nbBits[tid] : 0;
-            u32 pre = 0;
+            u32 nb[4], pre[4];
+            for (u32 k = 0; k < 4; ++k) { const u32 sIdx = k * 64 + lane; nb[k] = sIdx <= maxSV ? L.nbBits[sIdx] : 0; pre[k] = 0; }
             for (u32 r = 1; r <= 12; r++) {
-                const u64 b = ballot(nb == r);
-                if (lane == 0) L.rankCnt[r][wave] = popc64(b);
-                if (nb == r) pre = popc64(b & lanemask_lt());
+                u32 acc = 0;
+                for (u32 k = 0; k < 4; ++k) {
+                    const u64 b = ballot(nb[k] == r);
+                    if (nb[k] == r) pre[k] = acc + popc64(b & lanemask_lt());
+                    acc += popc64(b);
+                }
             }
-            __syncthreads();
-            u32 code = 0;
-            if (nb) { code = L.valPerRank[nb] + pre; for (u32 w = 0; w < wave; w++) code += L.rankCnt[nb][w]; }
-            T->nbBits[tid] = (u8)nb; T->code[tid] = (u16)code;
-            if (tid < maxSV) { const u32 wt = nb ? huffLog + 1 - nb : 0; L.weights[tid] = (u8)wt; atomicAdd(&L.wcount[wt], 1u); }   // HUF_writeCTable_wksp's bitsToWeight + the weights' histogram
+            for (u32 k = 0; k < 4; ++k) {
+                const u32 sIdx = k * 64 + lane;
+                const u32 code = nb[k] ? L.valPerRank[nb[k]] + pre[k] : 0;
+                T->nbBits[sIdx] = (u8)nb[k]; T->code[sIdx] = (u16)code;
+                if (sIdx < maxSV) { const u32 wt = nb[k] ? huffLog + 1 - nb[k] : 0; L.weights[sIdx] = (u8)wt; atomicAdd(&L.wcount[wt], 1u); }   // HUF_writeCTable_wksp's bitsToWeight + the weights' histogram
+            }
             // stream sizes = sum(count x nbBits) per segment (HUF_compress1X_usingCTable_internal + HUF_closeCStream)
-            u32 bits = 0;
-            for (u32 s = lane; s < 256; s += 64) bits += L.hist[wave][s] * L.nbBits[s];
-            bits = wave_sum(bits);
-            if (lane == 0) L.streamBits[wave] = bits;
+            for (u32 w = 0; w < 4; ++w) {
+                u32 bits = 0;
+                for (u32 k = 0; k < 4; ++k) bits += (u32)W->hist[w][k * 64 + lane] * nb[k];
+                streamBits[w] = wave_sum(bits);
+            }
         }
-        __syncthreads();
+        wave_lds_sync();
         ZMI_HSTAMP(6);
     }
     if (tid != 0) return;
 
     // ---------------- remaining serial section: tree description + decisions ----------------
-    bool compressed = L.sh[kShCompressed] != 0;
-    const bool rle = L.sh[kShRle] != 0;
+    bool compressed = shCompressed != 0;
+    const bool rle = shRle != 0;
     u32 hSize = 0, cLitSize = 0;
     u32 streamSize[4] = { 0, 0, 0, 0 };
     if (compressed) {
-        T->maxSV = maxSV; T->tableLog = L.sh[kShHuffLog];
+        T->maxSV = maxSV; T->tableLog = huffLog;
         const u32 ws = huf_compress_weights(L, T->hdr + 1, maxSV);
         if (ws > 1 && ws < maxSV / 2) { T->hdr[0] = (u8)ws; hSize = ws + 1; }
         else if (maxSV > 128) { compressed = false; }     // HUF_writeCTable_wksp fails -> ZSTD_compressLiterals stores raw
@@ -400,14 +477,14 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
     }
     if (compressed) {
         if (single) {
-            const u32 bits = L.streamBits[0] + L.streamBits[1] + L.streamBits[2] + L.streamBits[3];
+            const u32 bits = streamBits[0] + streamBits[1] + streamBits[2] + streamBits[3];
             streamSize[0] = (bits >> 3) + 1;
             cLitSize = hSize + streamSize[0];
         } else {
             if (litSize < 12) compressed = false;
             cLitSize = hSize + 6;
             for (u32 w = 0; w < 4 && compressed; w++) {
-                streamSize[w] = (L.streamBits[w] >> 3) + 1;
+                streamSize[w] = (streamBits[w] >> 3) + 1;
                 if (streamSize[w] > 65535) compressed = false;    // (a zero-length stream cannot occur: the end mark is a byte)
                 cLitSize += streamSize[w];
             }
@@ -420,14 +497,14 @@ __global__ __launch_bounds__(256) void huf_build_kernel(const u8* __restrict__ l
         for (int w = 0; w < 4; w++) m.streamSize[w] = streamSize[w];
         m.litSectionSize = lhSize + cLitSize;
     } else if (rle) {
-        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = L.sh[kShRleByte];
+        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = shRleByte;
     } else {
         m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize;
     }
     meta[c] = m;
     ZMI_HSTAMP(7);
 #ifdef ZMI_LZ_STAMPS
-    for (int i = 0; i < 10; i++) atomicAdd(&g_hufStamps[i], stampAcc[i]);
+    for (int i = 3; i < 10; i++) atomicAdd(&g_hufStamps[i], stampAcc[i]);
 #endif
 }
 
@@ -548,9 +625,10 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     }
 }
 
-void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u32 nChunks, hipStream_t stream)
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(huf_build_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables);
+    hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots);
+    hipLaunchKernelGGL(huf_tree_kernel, dim3(nChunks), dim3(64), 0, stream, meta, tables, slots);
 }
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream)
 {

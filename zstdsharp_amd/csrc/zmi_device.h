@@ -30,6 +30,8 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 v)
     for (int d = 1; d < 64; d <<= 1) { u32 t = __shfl_up(v, d); if ((int)lane_id() >= d) v += t; }
     return v;
 }
+// make one wave's LDS writes visible to its other lanes (single-wave workgroups need no s_barrier)
+__device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ u32 wave_sum(u32 v)
 {
 #pragma unroll

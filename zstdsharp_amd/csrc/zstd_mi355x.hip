@@ -15,7 +15,7 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream);
-void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u32 nChunks, hipStream_t stream);
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream);
 void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
@@ -176,7 +176,7 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         if (first) c->timer.begin(s);
         launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, s);                      if (first) c->timer.mark("lz_fast", s);
-        launch_huf_build(lits, meta, tables, nChunks, s);                          if (first) c->timer.mark("huf_build", s);
+        launch_huf_build(lits, meta, tables, slots, nChunks, s);                        if (first) c->timer.mark("huf_build", s);
         launch_huf_encode(lits, meta, tables, slots, nChunks, s);                  if (first) c->timer.mark("huf_encode", s);
         if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, s);             if (first) c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, s);   if (first) c->timer.mark("seq_encode", s);
@@ -600,7 +600,7 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (nbSeq) (void)hipMemcpyAsync(c->seqs.p, seqs, nbSeq * sizeof(Seq), hipMemcpyHostToDevice, s);
     if (litSize) (void)hipMemcpyAsync(c->lits.p, lits, litSize, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
-    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, 1, s);
+    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
     launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
     launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, strategy_for_level(c->level), 0, 0, s);
     if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
