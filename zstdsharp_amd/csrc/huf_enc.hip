@@ -43,6 +43,7 @@ struct HufTreeLds {
     u8  weights[256];
     u32 wcount[13]; s16 wnorm[13]; u16 wstate[64]; SymTT wtt[13]; u16 wcumul[15]; u8 wsym[64];
     u32 valPerRank[13];
+    u32 rankLast[14];
     u32 sh[8];
 };
 
@@ -138,59 +139,87 @@ __device__ inline int huf_build_tree(Node* huffNode, u32 maxSV, int* rootOut)
     return nonNullRank;
 }
 
-// ---- HUF_setMaxHeight (U/HufCompress.cs:377-514) ----
-__device__ inline u32 huf_set_max_height(Node* huffNode, u32 lastNonNull, u32 maxNbBits)
+// ---- HUF_setMaxHeight (U/HufCompress.cs:377-514), called by all 64 lanes of the chunk's wave ----
+// The three scans of the reference (clamp the over-long tail and total its cost; skip the run already at maxNbBits; find
+// the last symbol of every shorter length) are evaluated with ballots over the four positions each lane holds; only the
+// repayment loops, whose steps depend on each other, run on lane 0.  rankLast lives in LDS (it is indexed dynamically).
+template <class LDS>
+__device__ inline u32 huf_set_max_height_wave(LDS& L, Node* huffNode, u32 lastNonNull, u32 maxNbBits)
 {
+    const u32 lane = lane_id();
     const u32 largestBits = huffNode[lastNonNull].nbBits;
     if (largestBits <= maxNbBits) return largestBits;
-    int totalCost = 0; const u32 baseCost = 1u << (largestBits - maxNbBits); int n = (int)lastNonNull;
-    while (huffNode[n].nbBits > maxNbBits) {
-        totalCost += (int)(baseCost - (1u << (largestBits - huffNode[n].nbBits)));
-        huffNode[n].nbBits = (u8)maxNbBits; n--;
+    const u32 noSymbol = 0xF0F0F0F0u;
+    u32 nb[4];
+    for (u32 k = 0; k < 4; ++k) { const u32 pos = k * 64 + lane; nb[k] = pos <= lastNonNull ? huffNode[pos].nbBits : 0xFFu; }
+    auto highest = [&](bool p0, bool p1, bool p2, bool p3) -> int {       // highest position whose predicate holds, -1 if none
+        const u64 b3 = ballot(p3), b2 = ballot(p2), b1 = ballot(p1), b0 = ballot(p0);
+        if (b3) return 192 + 63 - __builtin_clzll(b3);
+        if (b2) return 128 + 63 - __builtin_clzll(b2);
+        if (b1) return 64 + 63 - __builtin_clzll(b1);
+        if (b0) return 63 - __builtin_clzll(b0);
+        return -1;
+    };
+    // loop 1: the tail of positions above n1 is longer than allowed
+    const int n1 = highest(nb[0] <= maxNbBits, nb[1] <= maxNbBits, nb[2] <= maxNbBits, nb[3] <= maxNbBits);
+    const u32 baseCost = 1u << (largestBits - maxNbBits);
+    int cost = 0;
+    for (u32 k = 0; k < 4; ++k) {
+        const int pos = (int)(k * 64 + lane);
+        if (pos > n1 && pos <= (int)lastNonNull) { cost += (int)(baseCost - (1u << (largestBits - nb[k]))); huffNode[pos].nbBits = (u8)maxNbBits; }
     }
-    while (huffNode[n].nbBits == maxNbBits) --n;
+    int totalCost = (int)wave_sum((u32)cost);
     totalCost >>= (largestBits - maxNbBits);
-    const u32 noSymbol = 0xF0F0F0F0; u32 rankLast[14];
-    for (int i = 0; i < 14; i++) rankLast[i] = noSymbol;
+    // loop 2: n = last position (<= n1) not already at maxNbBits
+    auto upTo = [&](u32 k, int lim) { return (int)(k * 64 + lane) <= lim; };
+    const int n = highest(upTo(0, n1) && nb[0] != maxNbBits, upTo(1, n1) && nb[1] != maxNbBits, upTo(2, n1) && nb[2] != maxNbBits, upTo(3, n1) && nb[3] != maxNbBits);
+    // loop 3: rankLast[maxNbBits - b] = last position of length b, if nothing shorter or equal sits above it
+    if (lane < 14) L.rankLast[lane] = noSymbol;
+    wave_lds_sync();
     {
-        u32 currentNbBits = maxNbBits;
-        for (int pos = n; pos >= 0; pos--) {
-            if (huffNode[pos].nbBits >= currentNbBits) continue;
-            currentNbBits = huffNode[pos].nbBits;
-            rankLast[maxNbBits - currentNbBits] = (u32)pos;
+        int above = -1;        // highest position (<= n) of any length smaller than b
+        for (u32 b = 1; b < maxNbBits; ++b) {
+            const int hi = highest(upTo(0, n) && nb[0] == b, upTo(1, n) && nb[1] == b, upTo(2, n) && nb[2] == b, upTo(3, n) && nb[3] == b);
+            if (hi >= 0 && hi > above && lane == 0) L.rankLast[maxNbBits - b] = (u32)hi;
+            if (hi > above) above = hi;
         }
     }
-    while (totalCost > 0) {
-        u32 nBitsToDecrease = highbit32((u32)totalCost) + 1;
-        for (; nBitsToDecrease > 1; nBitsToDecrease--) {
-            const u32 highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
-            if (highPos == noSymbol) continue;
-            if (lowPos == noSymbol) break;
-            const u32 highTotal = huffNode[highPos].count, lowTotal = 2 * huffNode[lowPos].count;
-            if (highTotal <= lowTotal) break;
+    wave_lds_sync();
+    if (lane == 0) {
+        u32* rankLast = L.rankLast; int nn = n;
+        while (totalCost > 0) {
+            u32 nBitsToDecrease = highbit32((u32)totalCost) + 1;
+            for (; nBitsToDecrease > 1; nBitsToDecrease--) {
+                const u32 highPos = rankLast[nBitsToDecrease], lowPos = rankLast[nBitsToDecrease - 1];
+                if (highPos == noSymbol) continue;
+                if (lowPos == noSymbol) break;
+                const u32 highTotal = huffNode[highPos].count, lowTotal = 2 * huffNode[lowPos].count;
+                if (highTotal <= lowTotal) break;
+            }
+            while (nBitsToDecrease <= 12 && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
+            totalCost -= 1 << (nBitsToDecrease - 1);
+            huffNode[rankLast[nBitsToDecrease]].nbBits++;
+            if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
+            if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
+            else {
+                rankLast[nBitsToDecrease]--;
+                if (huffNode[rankLast[nBitsToDecrease]].nbBits != maxNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
+            }
         }
-        while (nBitsToDecrease <= 12 && rankLast[nBitsToDecrease] == noSymbol) nBitsToDecrease++;
-        totalCost -= 1 << (nBitsToDecrease - 1);
-        huffNode[rankLast[nBitsToDecrease]].nbBits++;
-        if (rankLast[nBitsToDecrease - 1] == noSymbol) rankLast[nBitsToDecrease - 1] = rankLast[nBitsToDecrease];
-        if (rankLast[nBitsToDecrease] == 0) rankLast[nBitsToDecrease] = noSymbol;
-        else {
-            rankLast[nBitsToDecrease]--;
-            if (huffNode[rankLast[nBitsToDecrease]].nbBits != maxNbBits - nBitsToDecrease) rankLast[nBitsToDecrease] = noSymbol;
-        }
-    }
-    while (totalCost < 0) {
-        if (rankLast[1] == noSymbol) {
-            while (huffNode[n].nbBits == maxNbBits) n--;
-            huffNode[n + 1].nbBits--;
-            rankLast[1] = (u32)(n + 1);
+        while (totalCost < 0) {
+            if (rankLast[1] == noSymbol) {
+                while (huffNode[nn].nbBits == maxNbBits) nn--;
+                huffNode[nn + 1].nbBits--;
+                rankLast[1] = (u32)(nn + 1);
+                totalCost++;
+                continue;
+            }
+            huffNode[rankLast[1] + 1].nbBits--;
+            rankLast[1]++;
             totalCost++;
-            continue;
         }
-        huffNode[rankLast[1] + 1].nbBits--;
-        rankLast[1]++;
-        totalCost++;
     }
+    wave_lds_sync();
     return maxNbBits;
 }
 
@@ -215,18 +244,19 @@ __device__ inline u32 huf_compress_weights(HufTreeLds& L, u8* dst, u32 wtSize)
     // FSE_compress_usingCTable_generic (U/FseCompress.cs:722-820): symbol i uses state (i & 1), last symbol first
     if (wtSize <= 2) return 0;
     BitW bw; bw.init(op);
-    u32 st[2];
-    st[(wtSize - 1) & 1] = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 1]);
-    st[(wtSize - 2) & 1] = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 2]);
+    u32 st0 = 0, st1 = 0;          // (two named states: an indexed pair would live in scratch memory)
+    { const u32 v = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 1]); if ((wtSize - 1) & 1) st1 = v; else st0 = v; }
+    { const u32 v = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 2]); if ((wtSize - 2) & 1) st1 = v; else st0 = v; }
     for (u32 i = wtSize - 2; i-- > 0; ) {
         const SymTT t = L.wtt[L.weights[i]];
-        u32& v = st[i & 1];
+        u32 v = (i & 1) ? st1 : st0;
         const u32 nbBitsOut = (v + t.deltaNbBits) >> 16;
         bw.add(v, nbBitsOut);
         v = L.wstate[(s32)(v >> nbBitsOut) + t.deltaFindState];
+        if (i & 1) st1 = v; else st0 = v;
     }
-    bw.add(st[1], tableLog);
-    bw.add(st[0], tableLog);
+    bw.add(st1, tableLog);
+    bw.add(st0, tableLog);
     op = bw.close();
     return (u32)(op - dst);
 }
@@ -391,6 +421,7 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
     u32 huffLog = 0;
     u32 streamBits[4] = { 0, 0, 0, 0 };
     if (shCompressed) {
+#pragma unroll
         for (u32 k = 0; k < 4; ++k) {
             const u32 pos = k * 64 + lane;
             Node nd; nd.count = W->leafCount[pos]; nd.parent = 0; nd.byte = W->leafByte[pos]; nd.nbBits = 0;
@@ -407,38 +438,53 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
         wave_lds_sync();
         ZMI_HSTAMP(3);
         const u32 nonNull = L.sh[kShNonNull], root = L.sh[kShRoot];
+#pragma unroll
         for (u32 k = 0; k < 4; ++k) {   // depth of every leaf = number of parent links up to the root (HUF_buildTree's nbBits loops)
             const u32 pos = k * 64 + lane;
             if (pos <= nonNull) { u32 node = pos, d = 0; while (node != root) { node = huffNode[node].parent; d++; } huffNode[pos].nbBits = (u8)d; }
         }
         wave_lds_sync();
         ZMI_HSTAMP(4);
-        if (lane == 0) {
+        {
             u32 hl = fse_optimal_table_log(11, litSize, maxSV, 1);
-            hl = huf_set_max_height(huffNode, nonNull, hl);
-            u16 nbPerRank[13];
-            for (int i = 0; i < 13; i++) nbPerRank[i] = 0;
-            for (u32 n = 0; n <= nonNull; n++) nbPerRank[huffNode[n].nbBits]++;
-            { u16 mn = 0; for (int n = (int)hl; n > 0; n--) { L.valPerRank[n] = mn; mn += nbPerRank[n]; mn >>= 1; } }
-            L.valPerRank[0] = 0;
-            L.sh[kShHuffLog] = hl;
+            hl = huf_set_max_height_wave(L, huffNode, nonNull, hl);
+            // HUF_buildCTableFromTree: symbols per length, then the first code value of every length
+            u32 nbPerRank[13];
+            {
+                u32 nbk[4];
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) { const u32 pos = k * 64 + lane; nbk[k] = pos <= nonNull ? huffNode[pos].nbBits : 0xFFu; }
+#pragma unroll
+                for (u32 r = 0; r < 13; ++r) nbPerRank[r] = popc64(ballot(nbk[0] == r)) + popc64(ballot(nbk[1] == r)) + popc64(ballot(nbk[2] == r)) + popc64(ballot(nbk[3] == r));
+            }
+            if (lane == 0) {
+                u32 mn = 0;
+#pragma unroll
+                for (int r = 12; r > 0; r--) { if (r <= (int)hl) { L.valPerRank[r] = mn; mn += nbPerRank[r]; mn >>= 1; } }
+                L.valPerRank[0] = 0;
+                L.sh[kShHuffLog] = hl;
+            }
         }
         wave_lds_sync();
         ZMI_HSTAMP(5);
         huffLog = L.sh[kShHuffLog];
+#pragma unroll
         for (u32 k = 0; k < 4; ++k) { const u32 pos = k * 64 + lane; if (pos <= maxSV) L.nbBits[huffNode[pos].byte] = huffNode[pos].nbBits; }   // HUF_buildCTableFromTree
         wave_lds_sync();
         {   // canonical codes: symbols of one length get consecutive values in symbol order (U/HufCompress.cs:766-785)
             u32 nb[4], pre[4];
+#pragma unroll
             for (u32 k = 0; k < 4; ++k) { const u32 sIdx = k * 64 + lane; nb[k] = sIdx <= maxSV ? L.nbBits[sIdx] : 0; pre[k] = 0; }
             for (u32 r = 1; r <= 12; r++) {
                 u32 acc = 0;
+#pragma unroll
                 for (u32 k = 0; k < 4; ++k) {
                     const u64 b = ballot(nb[k] == r);
                     if (nb[k] == r) pre[k] = acc + popc64(b & lanemask_lt());
                     acc += popc64(b);
                 }
             }
+#pragma unroll
             for (u32 k = 0; k < 4; ++k) {
                 const u32 sIdx = k * 64 + lane;
                 const u32 code = nb[k] ? L.valPerRank[nb[k]] + pre[k] : 0;
@@ -446,8 +492,10 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
                 if (sIdx < maxSV) { const u32 wt = nb[k] ? huffLog + 1 - nb[k] : 0; L.weights[sIdx] = (u8)wt; atomicAdd(&L.wcount[wt], 1u); }   // HUF_writeCTable_wksp's bitsToWeight + the weights' histogram
             }
             // stream sizes = sum(count x nbBits) per segment (HUF_compress1X_usingCTable_internal + HUF_closeCStream)
+#pragma unroll
             for (u32 w = 0; w < 4; ++w) {
                 u32 bits = 0;
+#pragma unroll
                 for (u32 k = 0; k < 4; ++k) bits += (u32)W->hist[w][k * 64 + lane] * nb[k];
                 streamBits[w] = wave_sum(bits);
             }
@@ -483,7 +531,8 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
         } else {
             if (litSize < 12) compressed = false;
             cLitSize = hSize + 6;
-            for (u32 w = 0; w < 4 && compressed; w++) {
+#pragma unroll
+            for (u32 w = 0; w < 4; w++) {
                 streamSize[w] = (streamBits[w] >> 3) + 1;
                 if (streamSize[w] > 65535) compressed = false;    // (a zero-length stream cannot occur: the end mark is a byte)
                 cLitSize += streamSize[w];
@@ -494,7 +543,7 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
     }
     if (compressed) {
         m.litMode = kLitCompressed; m.litSingle = single; m.lhSize = lhSize; m.hufHdrSize = hSize;
-        for (int w = 0; w < 4; w++) m.streamSize[w] = streamSize[w];
+        m.streamSize[0] = streamSize[0]; m.streamSize[1] = streamSize[1]; m.streamSize[2] = streamSize[2]; m.streamSize[3] = streamSize[3];
         m.litSectionSize = lhSize + cLitSize;
     } else if (rle) {
         m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = shRleByte;
@@ -562,7 +611,7 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     }
     for (u32 i = tid; i < m.hufHdrSize; i += 256) body[m.lhSize + i] = T->hdr[i];
     u8* payload = body + m.lhSize + m.hufHdrSize;
-    if (!m.litSingle && tid < 3) writeLE16(payload + 2 * tid, m.streamSize[tid]);       // jump table
+    if (!m.litSingle && tid < 3) writeLE16(payload + 2 * tid, meta[c].streamSize[tid]);       // jump table
     __syncthreads();
 
     const u32 nStreams = m.litSingle ? 1 : 4;
@@ -571,7 +620,7 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     const u32 s0 = wave * seg;
     const u32 len = (wave == nStreams - 1) ? litSize - s0 : seg;
     u8* out = payload + (m.litSingle ? 0 : 6);
-    for (u32 w = 0; w < wave; w++) out += m.streamSize[w];
+    for (u32 w = 0; w < wave; w++) out += meta[c].streamSize[w];
     const u8* __restrict__ sym = lit + s0;
     u32* tile = L.tile[wave];
 
@@ -582,11 +631,15 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
         // lane handles reversed indices k0 + lane*8 .. +7  ->  source bytes len-1-k, descending
         const u32 kb = k0 + lane * kSymPerLane;
         u64 lo = 0, hi = 0; u32 nb = 0;
+        // the lane's 8 symbols sit in 8 consecutive bytes (descending): one unaligned 8-byte load when all are in range
+        const bool full8 = kb + kSymPerLane <= len;
+        const u64 pack = full8 ? *reinterpret_cast<const u64u*>(sym + (len - kSymPerLane - kb)) : 0;
 #pragma unroll
         for (u32 j = 0; j < kSymPerLane; j++) {
             const u32 k = kb + j;
             if (k < len) {
-                const u32 e = L.ct[sym[len - 1 - k]];
+                const u32 s8 = full8 ? (u32)(pack >> (8 * (kSymPerLane - 1 - j))) & 0xFFu : (u32)sym[len - 1 - k];
+                const u32 e = L.ct[s8];
                 const u64 code = e & 0xFFFF; const u32 b = e >> 16;
                 if (nb < 64) { lo |= code << nb; if (nb + b > 64) hi |= code >> (64 - nb); }
                 else hi |= code << (nb - 64);
