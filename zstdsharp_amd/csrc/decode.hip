@@ -798,6 +798,72 @@ struct SeqBits {
     __device__ __forceinline__ s32 remaining() const { return 8 * ptr + 64 - (s32)consumed; }
 };
 
+// Wave-uniform reader of the backward sequence bitstream, for the state chain.  Every member except the two windows is
+// the same in all lanes, so the compiler keeps it in SGPRs and the chain runs on the scalar unit.  The stream is seen as
+// dwords (dword d = stream bytes 4d..4d+3, zero outside the stream); lane l of `winCur` holds dword wbase + l, `winNext`
+// the 64 dwords below, fetched one window ahead; a dword enters `cont` through v_readlane, never through memory.
+struct SBits {
+    const u8* s; s32 size;
+    s32 pos;                    // bits not yet read (stream bit index of the next bit to read, exclusive); may go negative
+    s32 c0;                     // stream bit index of cont's bit 0; a multiple of 32
+    s32 wbase;
+    u64 cont;                   // stream bits [c0, c0 + 64)
+    u32 winCur, winNext;        // per lane
+    __device__ __forceinline__ u32 load_dword_z(s32 d) const
+    {
+        const s32 b = 4 * d;
+        if (b >= 0 && b + 4 <= size) return readLE32(s + b);
+        u32 v = 0;
+        for (s32 i = 0; i < 4; i++) { const s32 k = b + i; if (k >= 0 && k < size) v |= (u32)s[k] << (8 * i); }
+        return v;
+    }
+    __device__ __forceinline__ u32 dword(s32 d, u32 lane)       // d uniform, never more than one window below wbase
+    {
+        if (d < wbase) { winCur = winNext; wbase -= 64; winNext = load_dword_z(wbase - 64 + (s32)lane); }
+        return (u32)__builtin_amdgcn_readlane((int)winCur, d - wbase);
+    }
+    __device__ __forceinline__ bool init(const u8* p, s32 n, u32 lane)
+    {
+        s = p; size = n; pos = 0; c0 = 0; wbase = 0; cont = 0; winCur = 0; winNext = 0;
+        if (n < 1) return false;
+        const u32 last = uniform((u32)p[n - 1]);
+        if (!last) return false;
+        pos = (n - 1) * 8 + (s32)highbit32(last);
+        const s32 t = (pos - 1) >> 5;              // dword that holds the first bit to read (floor: -1 for an empty stream)
+        c0 = (t - 1) * 32; wbase = t - 63;
+        winCur = load_dword_z(wbase + (s32)lane); winNext = load_dword_z(wbase - 64 + (s32)lane);
+        const u32 lo = dword(t - 1, lane), hi = dword(t, lane);
+        cont = (u64)lo | ((u64)hi << 32);
+        return true;
+    }
+    // invariant between calls: 32 <= pos - c0 <= 64
+    __device__ __forceinline__ void refill(u32 lane) { c0 -= 32; cont = (cont << 32) | (u64)dword(c0 >> 5, lane); }
+    __device__ __forceinline__ u32 read(u32 nb, u32 lane)       // nb <= 32
+    {
+        const u32 v = nb ? (u32)(cont >> (u32)(pos - c0 - (s32)nb)) & (0xFFFFFFFFu >> (32 - nb)) : 0u;
+        pos -= (s32)nb;
+        if (pos - c0 < 32) refill(lane);
+        return v;
+    }
+    __device__ __forceinline__ void skip(u32 nb, u32 lane)      // nb <= 64
+    {
+        pos -= (s32)nb;
+        if (pos - c0 < 32) refill(lane);
+        if (pos - c0 < 32) refill(lane);
+    }
+    // bits [p - nb, p) of the stream for an arbitrary lane-private p (the extra-bit fields, read by the sequence's own lane)
+    __device__ __forceinline__ u32 field(s32 p, u32 nb) const
+    {
+        if (!nb) return 0;
+        const s32 q = p - (s32)nb, by = q >> 3;
+        u64 v;
+        if (by >= 0 && by + 8 <= size) v = readLE64(s + by);
+        else { v = 0; for (s32 i = 0; i < 8; i++) { const s32 k = by + i; if (k >= 0 && k < size) v |= (u64)s[k] << (8 * i); } }
+        return (u32)(v >> (u32)(q & 7)) & (0xFFFFFFFFu >> (32 - nb));
+    }
+};
+__device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | ((u64)uniform((u32)(v >> 32)) << 32); }
+
 // Sequences of one frame on one wave.  Per block: lane 0 runs the serial state chain (ZSTD_decodeSequence,
 // U/ZstdDecompressBlock.cs:2360-2484) 64 sequences at a time into LDS; then all 64 lanes execute the batch
 // (ZSTD_execSequence, :2187-2262): output positions by prefix sum, every lane copies its own sequence's literals and
@@ -872,51 +938,59 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
             // ---- sequences (ZSTD_decompressSequences_body, :2668-2763), 64 at a time ----
             u32 litPos = 0;
             if (nbSeq) {
-                SeqBits bd; u32 okInit = 1, sLL = 0, sOF = 0, sML = 0;
-                bd.s = nullptr; bd.size = 0; bd.ptr = 0; bd.lp = 0; bd.cont = 0; bd.raw = 0; bd.consumed = 0;
-                if (lane == 0) {
-                    okInit = bd.init(b + bp, (s32)(bend - bp)) ? 1u : 0u;
-                    if (okInit) { bd.rebase(); sLL = bd.read(L.llLog); sOF = bd.read(L.ofLog); sML = bd.read(L.mlLog); }
-                }
-                if (!uniform(okInit)) FAIL(kErrCorruption);
+                // The state chain (ZSTD_decodeSequence's three FSE updates, :2360-2484) only needs the LENGTHS of the extra-bit
+                // fields, so it runs wave-uniform on the scalar unit and records, per sequence, the three states and the bit
+                // position; each lane then reads the fields of its own sequence; repcodes are resolved in order afterwards.
+                SBits bd;
+                if (!bd.init(b + bp, (s32)(bend - bp), lane)) FAIL(kErrCorruption);
+                u32 sLL = bd.read(L.llLog, lane), sOF = bd.read(L.ofLog, lane), sML = bd.read(L.mlLog, lane);
                 for (u32 base = 0; base < nbSeq; base += 64) {
                     const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
-                    if (lane == 0) {
-                        for (u32 k = 0; k < cnt; k++) {     // ZSTD_decodeSequence (:2360-2484)
-                            const SeqSym ll = L.ll[sLL], ml = L.ml[sML], of = L.of[sOF];
-                            u32 matchLength = ml.baseValue, litLength = ll.baseValue, offset;
-                            bd.rebase();
-                            if (of.nbAddBits > 1) {
-                                offset = of.baseValue + bd.read(of.nbAddBits);
-                                rep2 = rep1; rep1 = rep0; rep0 = offset;
-                                if (of.nbAddBits > 24) bd.rebase();
-                            } else {
-                                const u32 ll0 = ll.baseValue == 0;
-                                if (of.nbAddBits == 0) {
-                                    offset = ll0 ? rep1 : rep0;
-                                    rep1 = ll0 ? rep0 : rep1;
-                                    rep0 = offset;
-                                } else {
-                                    const u32 code = of.baseValue + ll0 + bd.read(1);
-                                    u32 temp = code == 3 ? rep0 - 1 : (code == 1 ? rep1 : code == 2 ? rep2 : rep0);
-                                    temp += !temp;
-                                    if (code != 1) rep2 = rep1;
-                                    rep1 = rep0; rep0 = temp; offset = temp;
-                                }
+                    u32 recSt = 0; s32 recPos = 0;
+                    for (u32 k = 0; k < cnt; k++) {
+                        const u64 eLL = uniform64(*reinterpret_cast<const u64*>(&L.ll[sLL]));
+                        const u64 eML = uniform64(*reinterpret_cast<const u64*>(&L.ml[sML]));
+                        const u64 eOF = uniform64(*reinterpret_cast<const u64*>(&L.of[sOF]));
+                        const u32 pk = sLL | (sML << 10) | (sOF << 20);
+                        recSt = lane == k ? pk : recSt; recPos = lane == k ? bd.pos : recPos;
+                        // SeqSym = nextState:16 | nbAddBits:8 | nbBits:8 | baseValue:32
+                        bd.skip((((u32)eLL >> 16) & 0xFF) + (((u32)eML >> 16) & 0xFF) + (((u32)eOF >> 16) & 0xFF), lane);
+                        sLL = ((u32)eLL & 0xFFFF) + bd.read((u32)eLL >> 24, lane);
+                        sML = ((u32)eML & 0xFFFF) + bd.read((u32)eML >> 24, lane);
+                        sOF = ((u32)eOF & 0xFFFF) + bd.read((u32)eOF >> 24, lane);
+                    }
+                    // ---- every lane: the fields of its own sequence ----
+                    const bool have = lane < cnt;
+                    u32 ll = 0, ml = 0, off = 1, code = 4;      // code 4 = a real offset; 0..3 = repcode selector
+                    if (have) {
+                        const SeqSym qLL = L.ll[recSt & 1023], qML = L.ml[(recSt >> 10) & 1023], qOF = L.of[recSt >> 20];
+                        s32 p = recPos;
+                        const u32 ofv = bd.field(p, qOF.nbAddBits); p -= qOF.nbAddBits;
+                        const u32 mlv = bd.field(p, qML.nbAddBits); p -= qML.nbAddBits;
+                        const u32 llv = bd.field(p, qLL.nbAddBits);
+                        ll = qLL.baseValue + llv; ml = qML.baseValue + mlv;
+                        if (qOF.nbAddBits > 1) off = qOF.baseValue + ofv;
+                        else code = qOF.baseValue + (qLL.baseValue == 0) + ofv;     // ofv is 0 or the single extra bit
+                    }
+                    // ---- repcodes, in sequence order (wave-uniform) ----
+                    {
+                        const u64 repMask = ballot(have && code != 4);
+                        if (!repMask && cnt >= 3) {
+                            rep0 = read_lane(off, cnt - 1); rep1 = read_lane(off, cnt - 2); rep2 = read_lane(off, cnt - 3);
+                        } else {
+                            for (u32 k = 0; k < cnt; k++) {
+                                const u32 cd = read_lane(code, k);
+                                if (cd == 4) { const u32 o = read_lane(off, k); rep2 = rep1; rep1 = rep0; rep0 = o; }
+                                else if (cd != 0) {
+                                    u32 t = cd == 1 ? rep1 : (cd == 2 ? rep2 : rep0 - 1);
+                                    t += !t;
+                                    if (cd != 1) rep2 = rep1;
+                                    rep1 = rep0; rep0 = t;
+                                    off = lane == k ? t : off;
+                                } else off = lane == k ? rep0 : off;
                             }
-                            if (ml.nbAddBits) matchLength += bd.read(ml.nbAddBits);
-                            if (ll.nbAddBits) litLength += bd.read(ll.nbAddBits);
-                            if (bd.consumed > 64 - 26) bd.rebase();      // rare: long extra-bit fields; the three state reads need <= 26 bits
-                            sLL = ll.nextState + bd.read(ll.nbBits);
-                            sML = ml.nextState + bd.read(ml.nbBits);
-                            sOF = of.nextState + bd.read(of.nbBits);
-                            L.bLL[k] = litLength; L.bML[k] = matchLength; L.bOFF[k] = offset;
                         }
                     }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                    // ---- execute the batch (ZSTD_execSequence, :2187-2262) ----
-                    const bool have = lane < cnt;
-                    const u32 ll = have ? L.bLL[lane] : 0, ml = have ? L.bML[lane] : 0, off = have ? L.bOFF[lane] : 1;
                     const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
                     const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
                     if (totalLit > litSize - litPos) FAIL(kErrCorruption);
@@ -956,9 +1030,7 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                     }
                     op += totalOut; litPos += totalLit;
                 }
-                u32 leftover = 0;
-                if (lane == 0) leftover = bd.remaining() > 0;
-                if (uniform(leftover)) FAIL(kErrCorruption);          // bitstream not fully consumed (:2730-2733)
+                if (bd.pos > 0) FAIL(kErrCorruption);                 // bitstream not fully consumed (:2730-2733)
             }
             {
                 const u32 lastLL = litSize - litPos;
