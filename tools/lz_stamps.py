@@ -8,6 +8,8 @@ ffi.LIB_PATH = os.path.join(ROOT, "zstdsharp_amd", "libzstd_mi355x_stamps.so")
 lib = ffi.load()
 raw = ctypes.CDLL(ffi.LIB_PATH); raw.ZSTDMI_debugReadLzStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 raw.ZSTDMI_debugReadHufStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+raw.ZSTDMI_debugReadSeqStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+snames = ["other", "state chain", "fields+reps", "literals", "indep matches", "dependent matches"]
 hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
 names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense:init+rounds", "dense:finish+rank"]
 n = 256 << 20
@@ -25,3 +27,13 @@ for kind in ("zipf", "text"):
     raw.ZSTDMI_debugReadHufStamps(buf, 1)
     tot = sum(buf[i] for i in range(8))
     print(kind, "huf_build cycles/chunk", tot // chunks, {hnames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)
+    back = torch.empty(n, dtype=torch.uint8, device="cuda")
+    cs = lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
+    d = lib.ZSTD_createDCtx()
+    lib.ZSTDMI_decompressDevice(d, back.data_ptr(), n, dst.data_ptr(), cs)
+    raw.ZSTDMI_debugReadSeqStamps(buf, 1)
+    r = lib.ZSTDMI_decompressDevice(d, back.data_ptr(), n, dst.data_ptr(), cs)
+    raw.ZSTDMI_debugReadSeqStamps(buf, 1)
+    tot = sum(buf[i] for i in range(6))
+    print(kind, "decode_sequences cycles/chunk", tot // chunks, {snames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(6)},
+          "dependent matches per batch", round(buf[6] / max(buf[7], 1), 2), "batches/chunk", round(buf[7] / chunks, 1), "ok", r == n, flush=True)

@@ -751,6 +751,36 @@ __device__ __forceinline__ void wave_copy(u8* __restrict__ d, const u8* __restri
     const u32 done = chunks << 4;
     if (lane < n - done) d[done + lane] = s[done + lane];
 }
+// exact n-byte copy by ONE lane in 8-byte pieces (the last piece overlaps the one before instead of a byte tail);
+// source and destination do not overlap
+__device__ __forceinline__ void lane_copy(u8* __restrict__ d, const u8* __restrict__ s, u32 n)
+{
+    if (n >= 8) {
+        for (u32 i = 0; i + 8 < n; i += 8) *(u64u*)(d + i) = readLE64(s + i);
+        *(u64u*)(d + n - 8) = readLE64(s + n - 8);
+    } else if (n >= 4) {
+        const u32 a = readLE32(s), b = readLE32(s + n - 4);
+        *(u32u*)d = a; *(u32u*)(d + n - 4) = b;
+    } else if (n >= 2) {
+        const u32 a = readLE16(s), b = readLE16(s + n - 2);
+        writeLE16(d, a); writeLE16(d + n - 2, b);
+    } else if (n) d[0] = s[0];
+}
+// one lane's match of n bytes at distance `offset` (ZSTD_execSequence's overlap semantics): 8-byte pieces when the
+// distance allows it, bytes otherwise
+__device__ __forceinline__ void lane_match_copy(u8* d, u32 offset, u32 n)
+{
+    const u8* s0 = d - offset;
+    if (offset >= n) { lane_copy(d, s0, n); return; }
+    if (offset >= 8) {
+        // n > offset >= 8: pieces in order, each reading bytes that earlier pieces of this lane have written
+        u32 i = 0;
+        for (; i + 8 <= n; i += 8) *(u64u*)(d + i) = readLE64(s0 + i);
+        for (; i < n; i++) d[i] = s0[i];
+        return;
+    }
+    for (u32 i = 0; i < n; i++) d[i] = s0[i % offset];
+}
 // match copy with the byte-wise overlap semantics of ZSTD_execSequence (U/ZstdDecompressBlock.cs:2247-2259): byte i of
 // the match equals the byte `offset` behind it, i.e. src0[i % offset] over the bytes that existed before the match.
 __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 lane)
@@ -798,58 +828,53 @@ struct SeqBits {
     __device__ __forceinline__ s32 remaining() const { return 8 * ptr + 64 - (s32)consumed; }
 };
 
-// Wave-uniform reader of the backward sequence bitstream, for the state chain.  Every member except the two windows is
-// the same in all lanes, so the compiler keeps it in SGPRs and the chain runs on the scalar unit.  The stream is seen as
-// dwords (dword d = stream bytes 4d..4d+3, zero outside the stream); lane l of `winCur` holds dword wbase + l, `winNext`
-// the 64 dwords below, fetched one window ahead; a dword enters `cont` through v_readlane, never through memory.
+// Wave-uniform reader of the backward sequence bitstream, for the state chain.  The stream is seen as dwords (dword d =
+// stream bytes 4d..4d+3, zero outside the stream); lane l of `winCur` holds dword wbase + l and `winNext` the window 32
+// dwords lower, fetched one rotation ahead.  Bits are taken straight out of the window with two v_readlane and a scalar
+// 64-bit shift: no container to maintain, no refill branches, and the position arithmetic stays on the scalar unit
+// (which issues beside the vector unit: the chain is issue-bound, so the work is split between the two on purpose).
 struct SBits {
     const u8* s; s32 size;
-    s32 pos;                    // bits not yet read (stream bit index of the next bit to read, exclusive); may go negative
-    s32 c0;                     // stream bit index of cont's bit 0; a multiple of 32
+    s32 pos;                    // stream bit index one past the next bit to read; may go negative (reads zeros)
     s32 wbase;
-    u64 cont;                   // stream bits [c0, c0 + 64)
     u32 winCur, winNext;        // per lane
     __device__ __forceinline__ u32 load_dword_z(s32 d) const
     {
         const s32 b = 4 * d;
-        if (b >= 0 && b + 4 <= size) return readLE32(s + b);
+        if (size >= 4) {        // uniform; branch-free inside: clamp the address, then shift or zero what lies outside
+            const s32 hiB = size - 4;
+            const u32 v = readLE32(s + (b < 0 ? 0 : (b > hiB ? hiB : b)));
+            const u32 part = b > hiB ? (b < size ? v >> (8 * (u32)(b - hiB)) : 0u) : v;
+            return b < 0 ? 0u : part;
+        }
         u32 v = 0;
         for (s32 i = 0; i < 4; i++) { const s32 k = b + i; if (k >= 0 && k < size) v |= (u32)s[k] << (8 * i); }
         return v;
     }
-    __device__ __forceinline__ u32 dword(s32 d, u32 lane)       // d uniform, never more than one window below wbase
-    {
-        if (d < wbase) { winCur = winNext; wbase -= 64; winNext = load_dword_z(wbase - 64 + (s32)lane); }
-        return (u32)__builtin_amdgcn_readlane((int)winCur, d - wbase);
-    }
     __device__ __forceinline__ bool init(const u8* p, s32 n, u32 lane)
     {
-        s = p; size = n; pos = 0; c0 = 0; wbase = 0; cont = 0; winCur = 0; winNext = 0;
+        s = p; size = n; pos = 0; wbase = 0; winCur = 0; winNext = 0;
         if (n < 1) return false;
         const u32 last = uniform((u32)p[n - 1]);
         if (!last) return false;
         pos = (n - 1) * 8 + (s32)highbit32(last);
-        const s32 t = (pos - 1) >> 5;              // dword that holds the first bit to read (floor: -1 for an empty stream)
-        c0 = (t - 1) * 32; wbase = t - 63;
-        winCur = load_dword_z(wbase + (s32)lane); winNext = load_dword_z(wbase - 64 + (s32)lane);
-        const u32 lo = dword(t - 1, lane), hi = dword(t, lane);
-        cont = (u64)lo | ((u64)hi << 32);
+        wbase = ((pos - 1) >> 5) - 62;             // the dword holding the first bit sits at lane 62
+        winCur = load_dword_z(wbase + (s32)lane); winNext = load_dword_z(wbase - 32 + (s32)lane);
         return true;
     }
-    // invariant between calls: 32 <= pos - c0 <= 64
-    __device__ __forceinline__ void refill(u32 lane) { c0 -= 32; cont = (cont << 32) | (u64)dword(c0 >> 5, lane); }
+    // the 64 stream bits from bit q upward, q >= pos - 96 (the window is rotated when q falls below it)
+    __device__ __forceinline__ u64 peek(s32 q, u32 lane)
+    {
+        const s32 d = q >> 5;
+        if (d < wbase) { winCur = winNext; wbase -= 32; winNext = load_dword_z(wbase - 32 + (s32)lane); }
+        const u32 lo = (u32)__builtin_amdgcn_readlane((int)winCur, d - wbase);
+        const u32 hi = (u32)__builtin_amdgcn_readlane((int)winCur, d + 1 - wbase);
+        return (((u64)hi << 32) | lo) >> (u32)(q & 31);
+    }
     __device__ __forceinline__ u32 read(u32 nb, u32 lane)       // nb <= 32
     {
-        const u32 v = nb ? (u32)(cont >> (u32)(pos - c0 - (s32)nb)) & (0xFFFFFFFFu >> (32 - nb)) : 0u;
         pos -= (s32)nb;
-        if (pos - c0 < 32) refill(lane);
-        return v;
-    }
-    __device__ __forceinline__ void skip(u32 nb, u32 lane)      // nb <= 64
-    {
-        pos -= (s32)nb;
-        if (pos - c0 < 32) refill(lane);
-        if (pos - c0 < 32) refill(lane);
+        return nb ? (u32)peek(pos, lane) & (0xFFFFFFFFu >> (32 - nb)) : 0u;
     }
     // bits [p - nb, p) of the stream for an arbitrary lane-private p (the extra-bit fields, read by the sequence's own lane)
     __device__ __forceinline__ u32 field(s32 p, u32 nb) const
@@ -864,6 +889,13 @@ struct SBits {
 };
 __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | ((u64)uniform((u32)(v >> 32)) << 32); }
 
+#ifdef ZMI_LZ_STAMPS
+__device__ unsigned long long g_seqStamps[16];
+#define ZMI_SSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } while (0)
+#else
+#define ZMI_SSTAMP(i) do { } while (0)
+#endif
+
 // Sequences of one frame on one wave.  Per block: lane 0 runs the serial state chain (ZSTD_decodeSequence,
 // U/ZstdDecompressBlock.cs:2360-2484) 64 sequences at a time into LDS; then all 64 lanes execute the batch
 // (ZSTD_execSequence, :2187-2262): output positions by prefix sum, every lane copies its own sequence's literals and
@@ -873,6 +905,9 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                                       const u8* __restrict__ litIn, const u32 lane)
 {
 #define FAIL(code) return (code)
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
     u32 ip = h.headerSize, op = 0, litOff = 0;
     u32 rep0 = 1, rep1 = 4, rep2 = 8;
@@ -947,18 +982,23 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                 for (u32 base = 0; base < nbSeq; base += 64) {
                     const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
                     u32 recSt = 0; s32 recPos = 0;
+                    ZMI_SSTAMP(0);
                     for (u32 k = 0; k < cnt; k++) {
-                        const u64 eLL = uniform64(*reinterpret_cast<const u64*>(&L.ll[sLL]));
-                        const u64 eML = uniform64(*reinterpret_cast<const u64*>(&L.ml[sML]));
-                        const u64 eOF = uniform64(*reinterpret_cast<const u64*>(&L.of[sOF]));
+                        // SeqSym = nextState:16 | nbAddBits:8 | nbBits:8 | baseValue:32 ; only the first dword matters here
+                        const u32 vLL = *reinterpret_cast<const u32*>(&L.ll[sLL]), vML = *reinterpret_cast<const u32*>(&L.ml[sML]),
+                                  vOF = *reinterpret_cast<const u32*>(&L.of[sOF]);
                         const u32 pk = sLL | (sML << 10) | (sOF << 20);
                         recSt = lane == k ? pk : recSt; recPos = lane == k ? bd.pos : recPos;
-                        // SeqSym = nextState:16 | nbAddBits:8 | nbBits:8 | baseValue:32
-                        bd.skip((((u32)eLL >> 16) & 0xFF) + (((u32)eML >> 16) & 0xFF) + (((u32)eOF >> 16) & 0xFF), lane);
-                        sLL = ((u32)eLL & 0xFFFF) + bd.read((u32)eLL >> 24, lane);
-                        sML = ((u32)eML & 0xFFFF) + bd.read((u32)eML >> 24, lane);
-                        sOF = ((u32)eOF & 0xFFFF) + bd.read((u32)eOF >> 24, lane);
+                        const u32 eLL = uniform(vLL), eML = uniform(vML), eOF = uniform(vOF);
+                        const u32 nLL = eLL >> 24, nML = eML >> 24, nOF = eOF >> 24;
+                        bd.pos -= (s32)(((eLL >> 16) & 0xFF) + ((eML >> 16) & 0xFF) + ((eOF >> 16) & 0xFF));   // the extra-bit fields
+                        // the three state updates read LL, ML, OF bits in that order: one extraction, split afterwards
+                        const u32 all = bd.read(nLL + nML + nOF, lane);
+                        sLL = (vLL & 0xFFFF) + (all >> (nML + nOF));
+                        sML = (vML & 0xFFFF) + ((all >> nOF) & ~(0xFFFFFFFFu << nML));
+                        sOF = (vOF & 0xFFFF) + (all & ~(0xFFFFFFFFu << nOF));
                     }
+                    ZMI_SSTAMP(1);
                     // ---- every lane: the fields of its own sequence ----
                     const bool have = lane < cnt;
                     u32 ll = 0, ml = 0, off = 1, code = 4;      // code 4 = a real offset; 0..3 = repcode selector
@@ -991,6 +1031,7 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                             }
                         }
                     }
+                    ZMI_SSTAMP(2);
                     const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
                     const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
                     if (totalLit > litSize - litPos) FAIL(kErrCorruption);
@@ -1004,7 +1045,7 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                         const bool longLit = ll > 32;
                         if (have && !longLit) {
                             if (litIsRle) for (u32 i = 0; i < ll; i++) out[dLit + i] = (u8)rleByte;
-                            else for (u32 i = 0; i < ll; i++) out[dLit + i] = lit[sLit + i];
+                            else lane_copy(out + dLit, lit + sLit, ll);
                         }
                         u64 lm = ballot(have && longLit);
                         while (lm) {
@@ -1014,13 +1055,18 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                             else wave_copy(out + d0, lit + s0, n0, lane);
                         }
                     }
+                    ZMI_SSTAMP(3);
                     // matches whose source was complete before this batch: one lane each
                     const u32 srcEnd = dMatch - off + (off < ml ? off : ml);
                     const bool indep = have && srcEnd <= op && ml <= 32;
                     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // output of earlier batches (and this batch's literals) visible
-                    if (indep) { const u8* s0 = out + dMatch - off; if (off >= ml) { for (u32 i = 0; i < ml; i++) out[dMatch + i] = s0[i]; } else { for (u32 i = 0; i < ml; i++) out[dMatch + i] = s0[i % off]; } }
+                    if (indep) lane_match_copy(out + dMatch, off, ml);
+                    ZMI_SSTAMP(4);
                     // the others in sequence order, 64 lanes per match
                     u64 dm = ballot(have && !indep && ml != 0);
+#ifdef ZMI_LZ_STAMPS
+                    stampAcc[6] += popc64(dm); stampAcc[7] += 1;
+#endif
                     if (dm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     while (dm) {
                         const u32 i = ctz64(dm); dm &= dm - 1;
@@ -1029,6 +1075,7 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                         if (dm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                     }
                     op += totalOut; litPos += totalLit;
+                    ZMI_SSTAMP(5);
                 }
                 if (bd.pos > 0) FAIL(kErrCorruption);                 // bitstream not fully consumed (:2730-2733)
             }
@@ -1043,6 +1090,9 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
         }
         if (last) break;
     }
+#ifdef ZMI_LZ_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_seqStamps[i], stampAcc[i]);
+#endif
     if (op != fd.dstSize) FAIL(kErrCorruption);           // regenerated size must equal the header's FCS (U/ZstdDecompress.cs:1177-1184)
     if (h.checksum) {
         // XXH64 of the regenerated frame: accumulators on lanes 0..3 (U/ZstdDecompress.cs:1186-1208)
@@ -1260,5 +1310,13 @@ void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacit
 {
     hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch);
 }
+
+#ifdef ZMI_LZ_STAMPS
+extern "C" void ZSTDMI_debugReadSeqStamps(unsigned long long* out16, int reset)
+{
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seqStamps), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seqStamps), z, sizeof z); }
+}
+#endif
 
 } // namespace zmi
