@@ -227,61 +227,105 @@ __device__ inline u32 read_ncount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, co
 }
 
 // ZSTD_buildFSETable_body (U/ZstdDecompressBlock.cs:1571-1710), one lane
-__device__ inline void build_seq_dtable(SeqSym* t, u16* symbolNext, const s16* norm, u32 maxSV, u32 tableLog, int kind /*0 LL,1 OF,2 ML*/)
+__device__ __forceinline__ SeqSym seq_entry(u32 sym, u32 nextState, u32 tableLog, u32 tableSize, int kind)
 {
-    const u32 tableSize = 1u << tableLog; u32 highThreshold = tableSize - 1;
-    for (u32 s = 0; s <= maxSV; s++) {
-        if (norm[s] == -1) { t[highThreshold--].baseValue = s; symbolNext[s] = 1; }
-        else symbolNext[s] = (u16)norm[s];
-    }
-    {
-        const u32 mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3; u32 pos = 0;
-        for (u32 s = 0; s <= maxSV; s++)
-            for (int i = 0; i < norm[s]; i++) {
-                t[pos].baseValue = s;
-                pos = (pos + step) & mask;
-                while (pos > highThreshold) pos = (pos + step) & mask;
-            }
-    }
-    for (u32 u = 0; u < tableSize; u++) {
-        const u32 sym = t[u].baseValue, nextState = symbolNext[sym]++;
-        SeqSym e; e.nbBits = (u8)(tableLog - highbit32(nextState));
-        e.nextState = (u16)((nextState << e.nbBits) - tableSize);
-        if (kind == 0) { e.nbAddBits = dLL_bits[sym]; e.baseValue = dLL_base[sym]; }
-        else if (kind == 1) { e.nbAddBits = (u8)sym; e.baseValue = of_base(sym); }
-        else { e.nbAddBits = dML_bits[sym]; e.baseValue = dML_base[sym]; }
-        t[u] = e;
-    }
+    SeqSym e; e.nbBits = (u8)(tableLog - highbit32(nextState));
+    e.nextState = (u16)((nextState << e.nbBits) - tableSize);
+    if (kind == 0) { e.nbAddBits = dLL_bits[sym]; e.baseValue = dLL_base[sym]; }
+    else if (kind == 1) { e.nbAddBits = (u8)sym; e.baseValue = of_base(sym); }
+    else { e.nbAddBits = dML_bits[sym]; e.baseValue = dML_base[sym]; }
+    return e;
 }
 
-// ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), one lane.  Returns bytes consumed or 0xFFFFFFFF on error.
+// ZSTD_buildFSETable_body (U/ZstdDecompressBlock.cs:1571-1710) by all 64 lanes of the frame's wave; lane s stands for
+// symbol s (at most 53 symbols).  The reference's three serial passes become:
+//   low-probability symbols   -> the top cells, in symbol order (ballot rank);
+//   spreading                 -> the reference visits (i*step) & mask for i = 0, 1, 2, ... and skips cells above
+//                                highThreshold; the j-th cell it keeps goes to the symbol whose cumulative count covers j
+//                                (prefix count of kept cells, then a binary search in the cumulative counts);
+//   nextState = symbolNext++  -> cells are taken 64 at a time in index order; within a group the lanes that hold the
+//                                same symbol are ranked with a ballot, and the per-symbol counter lives in that symbol's lane.
+__device__ inline void build_seq_dtable_wave(SeqSym* t, u16* cum, const s16* norm, u32 maxSV, u32 tableLog, int kind, u32 lane)
+{
+    const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    const int nrm = lane <= maxSV ? (int)norm[lane] : 0;
+    const bool low = nrm == -1;
+    const u64 lowMask = ballot(low);
+    const u32 highThreshold = tableSize - 1 - popc64(lowMask);
+    if (low) t[tableSize - 1 - popc64(lowMask & lanemask_lt())].baseValue = lane;
+    const u32 cnt = nrm > 0 ? (u32)nrm : 0;
+    const u32 incl = wave_scan_incl(cnt);
+    cum[lane] = (u16)(incl - cnt);
+    wave_lds_sync();
+    u32 jBase = 0;
+    for (u32 i0 = 0; i0 < tableSize; i0 += 64) {
+        const u32 i = i0 + lane, p = (i * step) & mask;
+        const bool place = i < tableSize && p <= highThreshold;
+        const u64 bal = ballot(place);
+        const u32 j = jBase + popc64(bal & lanemask_lt());
+        jBase += popc64(bal);
+        if (place) {
+            u32 lo = 0, hi = 63;                 // largest symbol whose cumulative count is <= j
+#pragma unroll
+            for (u32 it = 0; it < 6; ++it) { const u32 mid = (lo + hi + 1) >> 1; if (cum[mid] <= j) lo = mid; else hi = mid - 1; }
+            t[p].baseValue = lo;
+        }
+    }
+    wave_lds_sync();
+    u32 nxt = low ? 1u : cnt;                    // symbolNext of symbol `lane`
+    for (u32 u0 = 0; u0 < tableSize; u0 += 64) {
+        const u32 u = u0 + lane; const bool valid = u < tableSize;
+        const u32 sym = valid ? t[u].baseValue : 0xFFFFu;
+        u32 myNext = 0;
+        u64 rem = ballot(valid);
+        while (rem) {
+            const u32 s0 = read_lane(sym, ctz64(rem));
+            const u64 m = ballot(sym == s0);
+            const u32 baseN = read_lane(nxt, s0);
+            if (sym == s0) myNext = baseN + popc64(m & lanemask_lt());
+            nxt = lane == s0 ? nxt + popc64(m) : nxt;
+            rem &= ~m;
+        }
+        wave_lds_sync();                         // every lane has read its cell's symbol before the cells are overwritten
+        if (valid) t[u] = seq_entry(sym, myNext, tableLog, tableSize, kind);
+    }
+    wave_lds_sync();
+}
+
+// ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), whole wave; only the NCount header is parsed by one lane.
+// Returns bytes consumed or 0xFFFFFFFF on error (uniform).
 __device__ inline u32 set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32* validPtr, u32 type, u32 max, u32 maxLog,
-                                    const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax)
+                                    const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax, u32 lane)
 {
     switch (type) {
     case 1: {
         if (!srcSize) return 0xFFFFFFFFu;
-        const u32 sym = src[0];
+        const u32 sym = uniform((u32)src[0]);
         if (sym > max) return 0xFFFFFFFFu;
-        SeqSym e; e.nextState = 0; e.nbBits = 0;
-        if (kind == 0) { e.nbAddBits = dLL_bits[sym]; e.baseValue = dLL_base[sym]; }
-        else if (kind == 1) { e.nbAddBits = (u8)sym; e.baseValue = of_base(sym); }
-        else { e.nbAddBits = dML_bits[sym]; e.baseValue = dML_base[sym]; }
-        t[0] = e; *logPtr = 0; *validPtr = 1;
+        if (lane == 0) {
+            SeqSym e = seq_entry(sym, 1, 0, 1, kind); e.nextState = 0; e.nbBits = 0;
+            t[0] = e; *logPtr = 0; *validPtr = 1;
+        }
+        wave_lds_sync();
         return 1; }
     case 0:
-        for (u32 s = 0; s <= defMax; s++) L.norm[s] = defNorm[s];
-        build_seq_dtable(t, L.symbolNext, L.norm, defMax, defLog, kind);
-        *logPtr = defLog; *validPtr = 1;
+        if (lane <= defMax) L.norm[lane] = defNorm[lane];
+        wave_lds_sync();
+        build_seq_dtable_wave(t, L.symbolNext, L.norm, defMax, defLog, kind, lane);
+        if (lane == 0) { *logPtr = defLog; *validPtr = 1; }
+        wave_lds_sync();
         return 0;
     case 3:
         return *validPtr ? 0 : 0xFFFFFFFFu;
     default: {
-        u32 maxSV = max, tableLog = 0;
-        const u32 hs = read_ncount(L.norm, &maxSV, &tableLog, src, srcSize);
+        u32 maxSV = max, tableLog = 0, hs = 0;
+        if (lane == 0) hs = read_ncount(L.norm, &maxSV, &tableLog, src, srcSize);
+        hs = uniform(hs); maxSV = uniform(maxSV); tableLog = uniform(tableLog);
         if (!hs || tableLog > maxLog) return 0xFFFFFFFFu;
-        build_seq_dtable(t, L.symbolNext, L.norm, maxSV, tableLog, kind);
-        *logPtr = tableLog; *validPtr = 1;
+        wave_lds_sync();
+        build_seq_dtable_wave(t, L.symbolNext, L.norm, maxSV, tableLog, kind, lane);
+        if (lane == 0) { *logPtr = tableLog; *validPtr = 1; }
+        wave_lds_sync();
         return hs; }
     }
 }
@@ -744,7 +788,19 @@ __device__ __forceinline__ void wave_copy(u8* __restrict__ d, const u8* __restri
 {
     if (n <= 64) { if (lane < n) d[lane] = s[lane]; return; }
     const u32 chunks = n >> 4;
-    for (u32 i = lane; i < chunks; i += 64) {
+    u32 i = lane;
+    // four 16-byte pieces per lane in flight (4 KiB per wave) before the first store: one load latency per 4 KiB, not per 1 KiB
+    for (; i + 192 < chunks; i += 256) {
+        const u64 a0 = readLE64(s + 16 * i), b0 = readLE64(s + 16 * i + 8);
+        const u64 a1 = readLE64(s + 16 * (i + 64)), b1 = readLE64(s + 16 * (i + 64) + 8);
+        const u64 a2 = readLE64(s + 16 * (i + 128)), b2 = readLE64(s + 16 * (i + 128) + 8);
+        const u64 a3 = readLE64(s + 16 * (i + 192)), b3 = readLE64(s + 16 * (i + 192) + 8);
+        *(u64u*)(d + 16 * i) = a0; *(u64u*)(d + 16 * i + 8) = b0;
+        *(u64u*)(d + 16 * (i + 64)) = a1; *(u64u*)(d + 16 * (i + 64) + 8) = b1;
+        *(u64u*)(d + 16 * (i + 128)) = a2; *(u64u*)(d + 16 * (i + 128) + 8) = b2;
+        *(u64u*)(d + 16 * (i + 192)) = a3; *(u64u*)(d + 16 * (i + 192) + 8) = b3;
+    }
+    for (; i < chunks; i += 64) {
         const u64 a = readLE64(s + 16 * i), b = readLE64(s + 16 * i + 8);
         *(u64u*)(d + 16 * i) = a; *(u64u*)(d + 16 * i + 8) = b;
     }
@@ -956,16 +1012,15 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                 if (bp + 1 > bend) FAIL(kErrSrcSizeWrong);
                 const u32 modes = b[bp++];
                 u32 adv = 0;
-                if (lane == 0) {
+                {
                     u32 p = bp, r;
-                    r = set_seq_table(L, L.ll, &L.llLog, &L.llValid, modes >> 6, 35, 9, b + p, bend - p, 0, dLL_defaultNorm, 6, 35);
+                    r = set_seq_table(L, L.ll, &L.llLog, &L.llValid, modes >> 6, 35, 9, b + p, bend - p, 0, dLL_defaultNorm, 6, 35, lane);
                     if (r == 0xFFFFFFFFu) adv = r; else { p += r;
-                    r = set_seq_table(L, L.of, &L.ofLog, &L.ofValid, (modes >> 4) & 3, 31, 8, b + p, bend - p, 1, dOF_defaultNorm, 5, 28);
+                    r = set_seq_table(L, L.of, &L.ofLog, &L.ofValid, (modes >> 4) & 3, 31, 8, b + p, bend - p, 1, dOF_defaultNorm, 5, 28, lane);
                     if (r == 0xFFFFFFFFu) adv = r; else { p += r;
-                    r = set_seq_table(L, L.ml, &L.mlLog, &L.mlValid, (modes >> 2) & 3, 52, 9, b + p, bend - p, 2, dML_defaultNorm, 6, 52);
+                    r = set_seq_table(L, L.ml, &L.mlLog, &L.mlValid, (modes >> 2) & 3, 52, 9, b + p, bend - p, 2, dML_defaultNorm, 6, 52, lane);
                     if (r == 0xFFFFFFFFu) adv = r; else { p += r; adv = p - bp; } } }
                 }
-                adv = uniform(adv);
                 if (adv == 0xFFFFFFFFu) FAIL(kErrCorruption);
                 bp += adv;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
@@ -1056,23 +1111,49 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                         }
                     }
                     ZMI_SSTAMP(3);
-                    // matches whose source was complete before this batch: one lane each
-                    const u32 srcEnd = dMatch - off + (off < ml ? off : ml);
-                    const bool indep = have && srcEnd <= op && ml <= 32;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // output of earlier batches (and this batch's literals) visible
-                    if (indep) lane_match_copy(out + dMatch, off, ml);
-                    ZMI_SSTAMP(4);
-                    // the others in sequence order, 64 lanes per match
-                    u64 dm = ballot(have && !indep && ml != 0);
+                    // ---- matches, in dependency rounds ----
+                    // A match may start once every earlier match of this batch whose output its source touches is complete
+                    // (literals of the batch and everything before the batch already are).  Each round runs all matches that
+                    // are ready: short ones by their own lane, long ones by the whole wave, then one fence.  The number of
+                    // rounds is the depth of the dependency chain, not the number of dependent matches.
+                    {
+                        const bool hasMatch = have && ml != 0;
+                        const u32 srcLo = dMatch - off, srcHi = srcLo + (off < ml ? off : ml);
+                        // earlier lanes whose match output overlaps my source: outputs are laid out in lane order, so they form
+                        // a lane interval [jl, jh) found by two binary searches over the (monotone) per-lane bounds
+                        const u64 mm = ballot(hasMatch);
+                        const u32 endOutX = have ? dMatch + ml : 0xFFFFFFFFu, dMatchX = have ? dMatch : 0xFFFFFFFFu;
+                        u32 jl = 0, jh = 0;
+#pragma unroll
+                        for (u32 st = 32; st; st >>= 1) {
+                            const u32 v0 = __shfl(endOutX, (int)(jl + st - 1)), v1 = __shfl(dMatchX, (int)(jh + st - 1));
+                            if (v0 <= srcLo) jl += st;
+                            if (v1 < srcHi) jh += st;
+                        }
+                        const u64 dep = (jh > jl ? ((~0ull >> (64 - (jh - jl))) << jl) : 0ull) & mm & lanemask_lt();
+                        u64 doneMask = ~mm;                            // lanes without a match never block anyone
+                        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // output of earlier batches and this batch's literals visible
+                        bool mine = hasMatch;
+                        ZMI_SSTAMP(4);
+                        while (doneMask != ~0ull) {
+                            const bool ready = mine && (dep & ~doneMask) == 0;
+                            const bool longM = ml > 64;
+                            if (ready && !longM) lane_match_copy(out + dMatch, off, ml);
+                            u64 lm = ballot(ready && longM);
+                            while (lm) {
+                                const u32 i = ctz64(lm); lm &= lm - 1;
+                                wave_match_copy(out + read_lane(dMatch, i), read_lane(off, i), read_lane(ml, i), lane);
+                            }
+                            const u64 r = ballot(ready);
+                            doneMask |= r; mine = mine && !ready;
+                            if (doneMask != ~0ull) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
 #ifdef ZMI_LZ_STAMPS
-                    stampAcc[6] += popc64(dm); stampAcc[7] += 1;
+                            stampAcc[6] += 1;
 #endif
-                    if (dm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    while (dm) {
-                        const u32 i = ctz64(dm); dm &= dm - 1;
-                        const u32 d0 = read_lane(dMatch, i), o0 = read_lane(off, i), n0 = read_lane(ml, i);
-                        wave_match_copy(out + d0, o0, n0, lane);
-                        if (dm) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                        }
+#ifdef ZMI_LZ_STAMPS
+                        stampAcc[7] += 1;
+#endif
                     }
                     op += totalOut; litPos += totalLit;
                     ZMI_SSTAMP(5);
