@@ -1095,19 +1095,43 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                     const u32 dMatch = dLit + ll;                       // where my match goes
                     const u32 sLit = litPos + inclLit - ll;
                     if (ballot(have && (off > dMatch || off == 0))) FAIL(kErrCorruption);
-                    // literals: short runs by their own lane, long runs by the whole wave
+                    // literals: short runs by their own lane; long runs are cut into 16-byte pieces (the last one overlapping the
+                    // one before, so every piece is whole) and ALL pieces of the batch are dealt to the lanes round-robin, four
+                    // in flight per lane: the copy is paced by bandwidth, not by one load-store round trip per run
                     {
                         const bool longLit = ll > 32;
                         if (have && !longLit) {
                             if (litIsRle) for (u32 i = 0; i < ll; i++) out[dLit + i] = (u8)rleByte;
                             else lane_copy(out + dLit, lit + sLit, ll);
                         }
-                        u64 lm = ballot(have && longLit);
-                        while (lm) {
-                            const u32 i = ctz64(lm); lm &= lm - 1;
-                            const u32 d0 = read_lane(dLit, i), s0 = read_lane(sLit, i), n0 = read_lane(ll, i);
-                            if (litIsRle) { for (u32 k2 = lane; k2 < n0; k2 += 64) out[d0 + k2] = (u8)rleByte; }
-                            else wave_copy(out + d0, lit + s0, n0, lane);
+                        if (litIsRle) {
+                            u64 lm = ballot(have && longLit);
+                            while (lm) {
+                                const u32 i = ctz64(lm); lm &= lm - 1;
+                                const u32 d0 = read_lane(dLit, i), n0 = read_lane(ll, i);
+                                for (u32 k2 = lane; k2 < n0; k2 += 64) out[d0 + k2] = (u8)rleByte;
+                            }
+                        } else if (ballot(have && longLit)) {
+                            const u32 pc = (have && longLit) ? (ll + 15) >> 4 : 0;
+                            const u32 pIncl = wave_scan_incl(pc), pExcl = pIncl - pc;
+                            const u32 P = read_lane(pIncl, 63);
+                            for (u32 q0 = 0; q0 < P; q0 += 256) {
+                                u64 a[4], b2[4]; u32 dd[4]; bool ok[4];
+#pragma unroll
+                                for (u32 t = 0; t < 4; ++t) {
+                                    const u32 q = q0 + t * 64 + lane;
+                                    ok[t] = q < P;
+                                    u32 j = 0;                       // the run that owns piece q: first lane whose inclusive count exceeds q
+#pragma unroll
+                                    for (u32 st = 32; st; st >>= 1) { const u32 v = __shfl(pIncl, (int)(j + st - 1)); if (v <= q) j += st; }
+                                    const u32 nj = __shfl(ll, (int)j), sj = __shfl(sLit, (int)j), dj = __shfl(dLit, (int)j), ej = __shfl(pExcl, (int)j);
+                                    u32 o = 16 * (q - ej); if (o + 16 > nj) o = nj - 16;
+                                    a[t] = 0; b2[t] = 0; dd[t] = dj + o;
+                                    if (ok[t]) { a[t] = readLE64(lit + sj + o); b2[t] = readLE64(lit + sj + o + 8); }
+                                }
+#pragma unroll
+                                for (u32 t = 0; t < 4; ++t) if (ok[t]) { *(u64u*)(out + dd[t]) = a[t]; *(u64u*)(out + dd[t] + 8) = b2[t]; }
+                            }
                         }
                     }
                     ZMI_SSTAMP(3);
