@@ -74,8 +74,12 @@ const char* ZSTD_getErrorName(size_t code);
 unsigned    ZSTD_versionNumber(void);        /* 10501, as U/ZstdCommon.cs:11-21 */
 const char* ZSTD_versionString(void);
 
-/* ---- streaming entry points of the safe API (S/Compressor.cs:114, S/Decompressor.cs:103): not part of this
- *      path yet; exported so the shim links, they return parameter_unsupported ---- */
+/* ---- streaming entry points of the safe API (S/Compressor.cs:108-116 <- S/CompressionStream.cs:130-190;
+ *      S/Decompressor.cs:97-106 <- S/DecompressionStream.cs:88-162; U/ZstdCompress.cs:6632-6861, U/ZstdDecompress.cs:2816-3205).
+ *      Adapters on the batched engine: input is collected on the host and goes through the one-shot
+ *      pipeline in batches (compress: 16 MiB or at flush/end; decompress: every whole frame received so far).  endOp is
+ *      ZSTD_EndDirective (0 continue, 1 flush, 2 end); return values follow the reference (bytes left to flush / 0 at a
+ *      frame boundary / hint), including the hostage-byte rule of U/ZstdDecompress.cs:3170-3194.  Host pointers only. ---- */
 typedef struct { const void* src; size_t size; size_t pos; } ZSTD_inBuffer;
 typedef struct { void* dst; size_t size; size_t pos; } ZSTD_outBuffer;
 size_t ZSTD_compressStream2(ZSTD_CCtx* cctx, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp);

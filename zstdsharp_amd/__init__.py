@@ -8,5 +8,6 @@ from .errors import ZstdException, ZSTD_ErrorCode
 from .compressor import Compressor
 from .decompressor import Decompressor
 from . import _ffi
+from .streams import CompressionStream, DecompressionStream, EndOfStreamException
 
-__all__ = ["Compressor", "Decompressor", "ZstdException", "ZSTD_ErrorCode", "_ffi"]
+__all__ = ["Compressor", "Decompressor", "CompressionStream", "DecompressionStream", "EndOfStreamException", "ZstdException", "ZSTD_ErrorCode", "_ffi"]

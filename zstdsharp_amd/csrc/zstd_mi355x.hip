@@ -8,6 +8,7 @@
 #include <string.h>
 #include <stdio.h>
 #include <vector>
+#include <cstring>
 #include <mutex>
 #include "zmi_common.h"
 #include "../../include/zstd_mi355x.h"
@@ -94,6 +95,8 @@ struct ZSTD_CCtx_s {
     DevBuf seqs, lits, meta, tables, slots, offsets, total, stageSrc, stageDst;
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
     u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
+    // streaming adapter (ZSTD_compressStream2): host-side batching in front of the one-shot engine
+    std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
     StageTimer timer;
     float stageMs[kMaxStages] = {}; const char* stageNames[kMaxStages] = {}; int nStages = 0;
 };
@@ -104,6 +107,8 @@ struct ZSTD_DCtx_s {
     hipStream_t ownStream = nullptr, stream = nullptr;
     DevBuf frames, status, frameErr, scratch, walkWs, slowFlags, stageSrc, stageDst;
     StageTimer timer;
+    // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
+    std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
 };
 
 
@@ -548,8 +553,110 @@ const char* ZSTD_getErrorName(size_t code)
 unsigned ZSTD_versionNumber(void) { return 10501; }
 const char* ZSTD_versionString(void) { return "1.5.1"; }
 
-size_t ZSTD_compressStream2(ZSTD_CCtx*, ZSTD_outBuffer*, ZSTD_inBuffer*, int) { return ZERR(kErrParameterUnsupported); }
-size_t ZSTD_decompressStream(ZSTD_DCtx*, ZSTD_outBuffer*, ZSTD_inBuffer*) { return ZERR(kErrParameterUnsupported); }
+// ---------------- streaming adapters on the batched engine ----------------
+// ZSTD_compressStream2 (S/Compressor.cs:108-116 <- S/CompressionStream.cs:130-190; U/ZstdCompress.cs:6632-6861).
+// Input is buffered on the host until a batch (16 MiB) is full or the caller flushes/ends; each batch goes through the
+// one-shot pipeline and comes back as complete, independent 64 KiB frames, so a flush point is a frame boundary and the
+// concatenation of everything emitted is one ordinary multi-frame zstd stream.  Return value as the reference's: for
+// e_flush / e_end the number of bytes still to be flushed (0 = done), for e_continue a non-zero hint.
+static size_t cstream_drain(ZSTD_CCtx* c, ZSTD_outBuffer* o)
+{
+    const size_t avail = c->sOut.size() - c->sOutPos, room = o->size - o->pos;
+    const size_t n = avail < room ? avail : room;
+    if (n) { memcpy((u8*)o->dst + o->pos, c->sOut.data() + c->sOutPos, n); o->pos += n; c->sOutPos += n; }
+    if (c->sOutPos == c->sOut.size()) { c->sOut.clear(); c->sOutPos = 0; }
+    return c->sOut.size() - c->sOutPos;
+}
+static size_t cstream_compress(ZSTD_CCtx* c, size_t n)      // first n buffered bytes -> appended to sOut
+{
+    const size_t cap = ZSTD_compressBound(n), at = c->sOut.size();
+    c->sOut.resize(at + cap);
+    const size_t r = ZSTD_compress2(c, c->sOut.data() + at, cap, c->sIn.data(), n);
+    if (isErr(r)) { c->sOut.resize(at); return r; }
+    c->sOut.resize(at + r);
+    c->sIn.erase(c->sIn.begin(), c->sIn.begin() + (ptrdiff_t)n);
+    return 0;
+}
+size_t ZSTD_compressStream2(ZSTD_CCtx* c, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp)
+{
+    if (!c || !output || !input) return ZERR(kErrGeneric);
+    if (output->pos > output->size) return ZERR(104);          // dstBuffer_wrong
+    if (input->pos > input->size) return ZERR(105);            // srcBuffer_wrong
+    if ((unsigned)endOp > 2) return ZERR(kErrParameterOutOfBound);
+    if (input->size > input->pos && !input->src) return ZERR(kErrSrcSizeWrong);
+    if (output->size > output->pos && !output->dst) return ZERR(kErrDstBufferNull);
+    if (cstream_drain(c, output)) return c->sOut.size() - c->sOutPos;       // output full: nothing consumed this time
+    if (!c->sEnding) {
+        const size_t n = input->size - input->pos;
+        if (n) { c->sIn.insert(c->sIn.end(), (const u8*)input->src + input->pos, (const u8*)input->src + input->size); input->pos = input->size; c->sWrote = true; }
+        size_t e = 0;
+        if (endOp == 0) {                                      // ZSTD_e_continue: whole chunks only, so that frames stay 64 KiB
+            if (c->sIn.size() >= c->sBatch) e = cstream_compress(c, c->sIn.size() / kChunkSize * kChunkSize);
+        } else {
+            if (!c->sIn.empty()) e = cstream_compress(c, c->sIn.size());
+            else if (endOp == 2 && !c->sWrote) {               // ZSTD_e_end on an empty stream: the empty frame (U/ZstdCompress.cs:5598-5656)
+                u8 tmp[16]; const size_t r = ZSTD_compress2(c, tmp, sizeof tmp, tmp, 0);
+                if (isErr(r)) e = r; else c->sOut.insert(c->sOut.end(), tmp, tmp + r);
+            }
+            if (endOp == 2) c->sEnding = true;
+        }
+        if (isErr(e)) return e;
+    }
+    const size_t left = cstream_drain(c, output);
+    if (c->sEnding && left == 0) { c->sEnding = false; c->sWrote = false; }    // frame session closed; the context may start another
+    if (endOp == 0) return left ? left : (c->sBatch > c->sIn.size() ? c->sBatch - c->sIn.size() : 1);
+    return left;
+}
+
+// ZSTD_decompressStream (S/Decompressor.cs:97-106 <- S/DecompressionStream.cs:88-162; U/ZstdDecompress.cs:2816-3205).
+// Compressed bytes are collected until at least one whole frame is present (frame sizes come from the block headers,
+// ZSTD_findFrameSizeInfo); all whole frames collected so far are decoded in one GPU batch into a pending buffer that is
+// handed out as the caller's output space allows.  Returns 0 when a frame boundary is reached and everything is flushed,
+// an error, or a non-zero hint.  As in the reference (U/ZstdDecompress.cs:3170-3194) the last input byte is held hostage
+// while decoded data is still pending, so that a caller who stops feeding at end of input still gets called back.
+static size_t dstream_drain(ZSTD_DCtx* d, ZSTD_outBuffer* o)
+{
+    const size_t avail = d->dOut.size() - d->dOutPos, room = o->size - o->pos;
+    const size_t n = avail < room ? avail : room;
+    if (n) { memcpy((u8*)o->dst + o->pos, d->dOut.data() + d->dOutPos, n); o->pos += n; d->dOutPos += n; }
+    if (d->dOutPos == d->dOut.size()) { d->dOut.clear(); d->dOutPos = 0; }
+    return d->dOut.size() - d->dOutPos;
+}
+size_t ZSTD_decompressStream(ZSTD_DCtx* d, ZSTD_outBuffer* output, ZSTD_inBuffer* input)
+{
+    if (!d || !output || !input) return ZERR(kErrGeneric);
+    if (output->pos > output->size) return ZERR(104);
+    if (input->pos > input->size) return ZERR(105);
+    if (input->size > input->pos && !input->src) return ZERR(kErrSrcSizeWrong);
+    if (output->size > output->pos && !output->dst) return ZERR(kErrDstBufferNull);
+    if (d->hostage && input->pos < input->size) { input->pos++; d->hostage = false; }       // that byte was consumed earlier
+    size_t pending = dstream_drain(d, output);
+    if (!pending) {
+        const size_t n = input->size - input->pos;
+        if (n) { d->dIn.insert(d->dIn.end(), (const u8*)input->src + input->pos, (const u8*)input->src + input->size); input->pos = input->size; }
+        size_t whole = 0; unsigned long long bound = 0;
+        while (whole < d->dIn.size()) {
+            unsigned long long b = 0;
+            const size_t fs = host_frame_size_info(d->dIn.data() + whole, d->dIn.size() - whole, &b);
+            if (isErr(fs)) { if (fs == ZERR(kErrSrcSizeWrong)) break; return fs; }          // incomplete frame: wait for more input
+            whole += fs; bound += b;
+        }
+        if (whole) {
+            d->dOut.resize((size_t)bound); d->dOutPos = 0;
+            const size_t r = ZSTD_decompressDCtx(d, d->dOut.data(), d->dOut.size(), d->dIn.data(), whole);
+            if (isErr(r)) { d->dOut.clear(); return r; }
+            d->dOut.resize(r);
+            d->dIn.erase(d->dIn.begin(), d->dIn.begin() + (ptrdiff_t)whole);
+            pending = dstream_drain(d, output);
+        }
+    }
+    if (pending) {
+        if (!d->hostage && input->pos == input->size && input->pos > 0) { input->pos--; d->hostage = true; }
+        return 1;
+    }
+    if (d->hostage) return 1;                                  // flushed, but the hostage byte has not been handed back yet
+    return d->dIn.empty() ? 0 : 1;                             // 0 only on a frame boundary
+}
 
 // ---------------- extensions ----------------
 int ZSTDMI_deviceCount(void) { return device_count(); }
