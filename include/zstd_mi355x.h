@@ -98,6 +98,10 @@ size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* dctx, void* hipStream);
 /* inputs larger than one pass are compressed pass by pass (default 16384 chunks = 1 GiB, which bounds the HBM workspace) */
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* cctx, unsigned chunksPerPass);
 
+/* literal (Huffman) decoder: 0 = chosen by frame count (default), 1 = serial, 4 lanes per frame (highest throughput when
+ * thousands of frames are in flight), 2 = self-synchronising, 256 lanes per frame (lowest latency per frame) */
+size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* dctx, unsigned mode);
+
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
 size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);
 size_t ZSTDMI_decompressDevice(ZSTD_DCtx* dctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);

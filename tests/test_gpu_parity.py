@@ -31,6 +31,15 @@ def ctxs(gpu_lib):
     c.Dispose(); d.Dispose()
 
 
+@pytest.fixture(scope="module", params=[1, 2], ids=["serial-literals", "selfsync-literals"])
+def forced_decoder(gpu_lib, request):
+    """Both literal decoders (the default picks one by frame count): 1 = 4 lanes per frame, 2 = 256 lanes per frame."""
+    d = z.Decompressor()
+    assert gpu_lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, request.param) == 0
+    yield d
+    d.Dispose()
+
+
 @pytest.mark.parametrize("kind", datagen.KINDS)
 def test_round_trip_matrix(ctxs, oracle, kind):
     c, d = ctxs
@@ -53,6 +62,25 @@ def test_gpu_decoder_on_golden_frames(ctxs, golden):
         blob = open(c["path"], "rb").read()
         out = d.Unwrap(blob)
         assert hashlib.sha256(out).hexdigest() == c["sha256"], c["file"]
+
+
+def test_both_literal_decoders_on_golden_and_oracle_frames(forced_decoder, ctxs, oracle, golden):
+    d = forced_decoder
+    for c in golden:
+        out = d.Unwrap(open(c["path"], "rb").read())
+        assert hashlib.sha256(out).hexdigest() == c["sha256"], c["file"]
+    comp = ctxs[0]
+    for kind in datagen.KINDS:
+        for n in (1, 255, 256, 1000, 65536, 65537, 200001):
+            data = datagen.gen(kind, n, n + 3)
+            assert d.Unwrap(comp.Wrap(data)) == data, (kind, n)
+            for level in (1, 3, 5):
+                ref = oracle.compress(data, level, 1, 65536)
+                if isinstance(ref, int):
+                    assert ref == -40 and level == 5          # the oracle refuses greedy/lazy without the row hash (windowLog <= 14)
+                    continue
+                assert d.Unwrap(ref) == data, (kind, n, level)
+            assert d.Unwrap(oracle.compress(data, 1, 0, 0)) == data, (kind, n, "one multi-block frame")
 
 
 def test_generate_buffer_sizes_with_reused_contexts(ctxs):

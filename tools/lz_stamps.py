@@ -37,3 +37,4 @@ for kind in ("zipf", "text"):
     tot = sum(buf[i] for i in range(6))
     print(kind, "decode_sequences cycles/chunk", tot // chunks, {snames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(6)},
           "dependent matches per batch", round(buf[6] / max(buf[7], 1), 2), "batches/chunk", round(buf[7] / chunks, 1), "ok", r == n, flush=True)
+    print(kind, "literal streams: passes/stream", round(buf[8] / max(buf[9], 1), 2), "sync cycles/stream", buf[10] // max(buf[9], 1), "write cycles/stream", buf[11] // max(buf[9], 1), flush=True)

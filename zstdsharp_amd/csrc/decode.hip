@@ -140,6 +140,13 @@ struct BackBits {
 // ------------------------------------------------------------------------------------------------
 // per-wave decoder state in LDS
 // ------------------------------------------------------------------------------------------------
+#ifdef ZMI_LZ_STAMPS
+__device__ unsigned long long g_seqStamps[16];
+#define ZMI_SSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } while (0)
+#else
+#define ZMI_SSTAMP(i) do { } while (0)
+#endif
+
 struct SeqSym { u16 nextState; u8 nbAddBits; u8 nbBits; u32 baseValue; };
 
 // literals kernel: 5.5 KiB per wave
@@ -945,12 +952,6 @@ struct SBits {
 };
 __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | ((u64)uniform((u32)(v >> 32)) << 32); }
 
-#ifdef ZMI_LZ_STAMPS
-__device__ unsigned long long g_seqStamps[16];
-#define ZMI_SSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } while (0)
-#else
-#define ZMI_SSTAMP(i) do { } while (0)
-#endif
 
 // Sequences of one frame on one wave.  Per block: lane 0 runs the serial state chain (ZSTD_decodeSequence,
 // U/ZstdDecompressBlock.cs:2360-2484) 64 sequences at a time into LDS; then all 64 lanes execute the batch
@@ -1404,9 +1405,271 @@ void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32
 {
     hipLaunchKernelGGL(frame_walk_serial_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status);
 }
-void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
-                            u8* slowFlags, hipStream_t stream)
+// =====================================================================================================================
+// Literal decoder, self-synchronising form (rows a-15, a-16): one 256-thread workgroup per frame, wave w decodes Huffman
+// stream w with ALL 64 lanes.  A Huffman stream has no random access, but decoding started at an arbitrary bit falls
+// into step with the true codeword boundaries after a few symbols.  So the stream's bits are cut into 64 spans, one per
+// lane; every lane decodes its span from a guessed start, then restarts from the position where the lane above it
+// really ended, until no start changes any more (lane 0's start is exact, so this converges; two or three passes in
+// practice).  The symbol counts then give every lane its output offset, and a last pass writes the symbols.  One 8 KiB
+// table per frame serves 256 lookup chains instead of 4, which is what the serial form could not have (LDS capacity).
+// Accepts what HUF_decompress4X1/1X1 accept (U/HufDecompress.cs:264-537): tableLog <= 12, every stream consumed exactly.
+// =====================================================================================================================
+constexpr u32 kStageBytes = 16384;
+struct SyncLds {
+    u16 huf[4096];              // X1 table: byte | nbBits << 8.  Before it is filled its storage holds the FSE scratch.
+    u8  weights[256];
+    u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded
+    u32 classStart[14];         // first table index of weight class w; [tableLog + 1] = table size
+    u32 classFirst[14];         // index into sorted[] of the first symbol of class w
+    u32 meta[4];
+    u32 err;
+    // one compressed stream per wave, staged with coalesced loads: the spans' containers are then refilled from LDS (per-lane
+    // 8-byte global loads cost one cache-line request per lane per refill, which is what bounded the serial decoder too).
+    // Bytes [0, 8) are zero: reads below the start of the stream.
+    u8  stage[4][kStageBytes];
+};
+
+// Decode the span (lo, p] of a stream from a start position p (codeword boundary or guess) down to the first boundary at
+// or below lo.  `sb` points at stream byte 0 (LDS stage + 8, or global memory when the stream did not fit the stage;
+// then `size` bounds the reads).  WRITE: symbols go to out[0..), 16 per store.
+template <bool WRITE, bool STAGED>
+__device__ __forceinline__ void huf_span(const u16* __restrict__ table, const u32 tableLog, const u8* __restrict__ sb, const s32 size,
+                                         s32 p, const s32 lo, u8* __restrict__ out, s32& endOut, u32& cntOut)
 {
+    u32 cnt = 0;
+    if (p > lo) {
+        s32 ptr = ((p + 7) >> 3) - 8;                       // container = stream bytes [ptr, ptr + 8), ptr >= -7
+        u32 consumed = (u32)(8 * (ptr + 8) - p);            // bits of the container already used (0..7)
+        auto load8 = [&](s32 idx) -> u64 {
+            if (STAGED) return readLE64(sb + idx);          // the stage has 8 zero bytes below the stream
+            if (idx >= 0 && idx + 8 <= size) return readLE64(sb + idx);
+            u64 v = 0;
+            for (s32 i = 0; i < 8; i++) { const s32 k = idx + i; if (k >= 0 && k < size) v |= (u64)sb[k] << (8 * i); }
+            return v;
+        };
+        const u32 sh = 32 - tableLog;
+        bool more = true;
+        while (more) {
+            u32 w4[4] = { 0, 0, 0, 0 }; u32 k = 0;
+#pragma unroll
+            for (u32 g = 0; g < 4; ++g) {
+                if (more) {
+                    const u64 cont = load8(ptr);
+                    const u32 limit = (u32)(8 * (ptr + 8) - lo);        // the span ends once consumed >= limit
+#pragma unroll
+                    for (u32 j = 0; j < 4; ++j) {
+                        if (more) {
+                            const u32 e = table[(u32)((cont << consumed) >> 32) >> sh];
+                            consumed += e >> 8; ++k;
+                            if (WRITE) w4[g] |= (e & 0xFFu) << (8 * j);
+                            more = consumed < limit;
+                        }
+                    }
+                    ptr -= (s32)(consumed >> 3); consumed &= 7;
+                }
+            }
+            if (WRITE) {
+                if (k == 16) { u32u* o = (u32u*)(out + cnt); o[0] = w4[0]; o[1] = w4[1]; o[2] = w4[2]; o[3] = w4[3]; }
+                else for (u32 j = 0; j < k; ++j) out[cnt + j] = (u8)(w4[j >> 2] >> (8 * (j & 3)));
+            }
+            cnt += k;
+        }
+        p = 8 * (ptr + 8) - (s32)consumed;
+    }
+    endOut = p; cntOut = cnt;
+}
+
+// one stream on one wave; true iff it decodes to exactly n symbols and is consumed to its first bit
+template <bool STAGED>
+__device__ __forceinline__ bool huf_stream_passes(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ sb, u32 srcSize, u32 last,
+                                                  u8* __restrict__ out, u32 n, u32 lane)
+{
+    const s32 P0 = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+    s32 span = (P0 + 63) / 64; if (span < 128) span = 128;              // >= 10 codewords per span
+    const s32 hi = P0 - (s32)lane * span;                                // my upper boundary (first guess of my start)
+    const s32 lo = hi - span > 0 ? hi - span : 0;
+    s32 start = hi, end = hi; u32 cnt = 0;
+    bool dirty = true;
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long t0 = __builtin_amdgcn_s_memtime(); u32 nPass = 0;
+#endif
+    for (u32 pass = 0; pass < 66; ++pass) {
+        if (dirty) huf_span<false, STAGED>(table, tableLog, sb, (s32)srcSize, start, lo, nullptr, end, cnt);
+        s32 ns = __shfl_up(end, 1);
+        if (lane == 0) ns = P0;
+        dirty = ns != start;
+        start = ns;
+#ifdef ZMI_LZ_STAMPS
+        ++nPass;
+#endif
+        if (!ballot(dirty)) break;
+    }
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long t1 = __builtin_amdgcn_s_memtime();
+#endif
+    const u32 incl = wave_scan_incl(cnt);
+    const u32 total = read_lane(incl, 63);
+    const s32 finalEnd = (s32)read_lane((u32)end, 63);
+    if (total != n || finalEnd != 0) return false;
+    s32 e2; u32 c2;
+    huf_span<true, STAGED>(table, tableLog, sb, (s32)srcSize, start, lo, out + (incl - cnt), e2, c2);
+#ifdef ZMI_LZ_STAMPS
+    if (lane == 0) { atomicAdd(&g_seqStamps[8], (unsigned long long)nPass); atomicAdd(&g_seqStamps[9], 1ull); atomicAdd(&g_seqStamps[10], t1 - t0); atomicAdd(&g_seqStamps[11], __builtin_amdgcn_s_memtime() - t1); }
+#endif
+    return true;
+}
+__device__ bool huf_decode_stream_sync(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ src, u32 srcSize,
+                                       u8* __restrict__ out, u32 n, u32 lane, u8* __restrict__ stage)
+{
+    if (srcSize < 1) return false;
+    const u32 last = uniform((u32)src[srcSize - 1]);
+    if (!last) return false;
+    if (srcSize + 8 <= kStageBytes) {
+        // stage: [0,8) zeros, then the stream; 16 bytes per lane per step
+        if (lane < 2) reinterpret_cast<u32*>(stage)[lane] = 0;
+        for (u32 i = lane * 16; i < srcSize; i += 1024) {
+            if (i + 16 <= srcSize) { const u64 a = readLE64(src + i), b = readLE64(src + i + 8); *(u64u*)(stage + 8 + i) = a; *(u64u*)(stage + 16 + i) = b; }
+            else for (u32 k = i; k < srcSize; ++k) stage[8 + k] = src[k];
+        }
+        wave_lds_sync();
+        const bool ok = huf_stream_passes<true>(table, tableLog, stage + 8, srcSize, last, out, n, lane);
+        wave_lds_sync();
+        return ok;
+    }
+    return huf_stream_passes<false>(table, tableLog, src, srcSize, last, out, n, lane);
+}
+
+__device__ u32 sync_decode_literals(SyncLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 tid)
+{
+    const u32 lane = tid & 63, wave = tid >> 6;
+    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
+    u32 ip = h.headerSize, litOff = 0;
+    bool haveTable = false; u32 tableLog = 0;
+    for (;;) {
+        if (fd.srcSize - ip < 3) return kErrSrcSizeWrong;
+        const u32 bh = readLE24(fsrc + ip);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        ip += 3;
+        if (type == 3) return kErrCorruption;
+        if (type == 1) { if (1 > fd.srcSize - ip) return kErrSrcSizeWrong; ip += 1; }
+        else {
+            if (bsz > fd.srcSize - ip) return kErrSrcSizeWrong;
+            if (type == 2) {
+                if (bsz >= kBlockMax) return kErrSrcSizeWrong;
+                if (bsz < 3) return kErrCorruption;
+                const u8* const b = fsrc + ip;
+                const LitHeader lh = parse_lit_header(b, bsz);
+                if (lh.err) return lh.err;
+                if (lh.type >= 2) {
+                    if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
+                    const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
+                    if (lh.type == 2) {
+                        __syncthreads();                               // the previous block's streams are done with the table
+                        if (tid == 0) {
+                            QuadScratch sc;
+                            sc.weights = L.weights; sc.norm = reinterpret_cast<s16*>(L.huf); sc.symbolNext = L.huf + 256;
+                            sc.wNewState = L.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(L.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(L.huf + 608);
+                            u32 nbSymbols = 0, tl = 0;
+                            const u32 hs = huf_read_stats(sc, hsrc, hlen, &nbSymbols, &tl);
+                            L.meta[0] = hs; L.meta[1] = nbSymbols; L.meta[2] = tl; L.err = 0;
+                        }
+                        __syncthreads();
+                        const u32 hs = L.meta[0], nbSymbols = L.meta[1]; tableLog = L.meta[2];
+                        if (!hs || hs >= hlen) return kErrCorruption;
+                        if (tableLog > 12) return kErrTableLogTooLarge;
+                        if (wave == 0) {       // HUF_readDTableX1_wksp (U/HufDecompress.cs:80-251): symbols by (weight, symbol), class extents
+                            u32 wk[4], pos[4];
+#pragma unroll
+                            for (u32 k = 0; k < 4; ++k) { const u32 sI = k * 64 + lane; wk[k] = sI < nbSymbols ? L.weights[sI] : 0; pos[k] = 0; }
+                            u32 symBase = 0, idxBase = 0;
+                            for (u32 w = 1; w <= tableLog; ++w) {
+                                if (lane == 0) { L.classStart[w] = idxBase; L.classFirst[w] = symBase; }
+                                u32 acc = 0;
+#pragma unroll
+                                for (u32 k = 0; k < 4; ++k) {
+                                    const u64 bm = ballot(wk[k] == w);
+                                    if (wk[k] == w) pos[k] = symBase + acc + popc64(bm & lanemask_lt());
+                                    acc += popc64(bm);
+                                }
+                                symBase += acc; idxBase += acc << (w - 1);
+                            }
+                            if (lane == 0) L.classStart[tableLog + 1] = idxBase;
+#pragma unroll
+                            for (u32 k = 0; k < 4; ++k) if (wk[k]) L.sorted[pos[k]] = (u8)(k * 64 + lane);
+                        }
+                        __syncthreads();
+                        {
+                            const u32 tableSize = 1u << tableLog;
+                            if (L.classStart[tableLog + 1] != tableSize) return kErrCorruption;      // (huf_read_stats guarantees it; cheap to keep)
+                            for (u32 e = tid; e < tableSize; e += 256) {
+                                u32 w = 1;
+                                for (u32 c = 2; c <= tableLog; ++c) if (L.classStart[c] <= e) w = c;
+                                const u32 sym = L.sorted[L.classFirst[w] + ((e - L.classStart[w]) >> (w - 1))];
+                                L.huf[e] = (u16)(sym | ((tableLog + 1 - w) << 8));
+                            }
+                        }
+                        __syncthreads();
+                        haveTable = true;
+                        hsrc += hs; hlen -= hs;
+                    } else if (!haveTable) return kErrDictionaryCorrupted;
+                    u8* const dst = litOut + litOff;
+                    bool ok = true;
+                    if (lh.single) {
+                        if (wave == 0) ok = huf_decode_stream_sync(L.huf, tableLog, hsrc, hlen, dst, lh.litSize, lane, L.stage[0]);
+                    } else {
+                        if (hlen < 10) return kErrCorruption;
+                        const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
+                        const u32 seg = (lh.litSize + 3) / 4;
+                        if (6 + l1 + l2 + l3 > hlen) return kErrCorruption;
+                        if (seg * 3 > lh.litSize) return kErrCorruption;
+                        const u32 l4 = hlen - 6 - l1 - l2 - l3;
+                        const u32 so = wave == 0 ? 6 : wave == 1 ? 6 + l1 : wave == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
+                        const u32 sl = wave == 0 ? l1 : wave == 1 ? l2 : wave == 2 ? l3 : l4;
+                        const u32 on = wave < 3 ? seg : lh.litSize - 3 * seg;
+                        ok = huf_decode_stream_sync(L.huf, tableLog, hsrc + so, sl, dst + wave * seg, on, lane, L.stage[wave]);
+                    }
+                    if (!ok && lane == 0) L.err = 1;
+                    __syncthreads();
+                    if (L.err) return kErrCorruption;
+                    litOff += lh.litSize;
+                }
+            }
+            ip += bsz;
+        }
+        if (last) break;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
+                                                                   u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 syncLdsRaw[];
+    SyncLds& L = *reinterpret_cast<SyncLds*>(syncLdsRaw);
+    const u32 f = blockIdx.x, tid = threadIdx.x;
+    if (f >= nFrames) return;
+    const FrameDesc fd = frames[f];
+    if (tid == 0) L.err = 0;
+    if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (tid == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
+    __syncthreads();
+    const u32 err = sync_decode_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, tid);
+    if (err && tid == 0) atomicCAS(frameErr, 0u, err);
+}
+
+// Two literal decoders.  The serial one (4 lanes per frame) has the fewest instructions per symbol and wins once there
+// are enough frames to fill the chip (one round = 8192 frames: 1.0-1.7 ms for 16..8192 frames, 3.5 ms for 16384); the
+// self-synchronising one (256 lanes per frame) takes 0.18 ms up to 256 frames and 0.34 ms per 1000 frames beyond.  mode: 0 = choose by frame count, 1 = serial, 2 = self-synchronising.
+void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
+                            u8* slowFlags, u32 mode, hipStream_t stream)
+{
+    const bool sync = mode == 2 || (mode == 0 && nFrames <= 4096);      // measured crossover ~4400 frames (tools/lit_decoder_crossover.py)
+    if (sync) {
+        static bool attrSet = false;
+        if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_literals_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SyncLds)); attrSet = true; }
+        hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nFrames), dim3(256), sizeof(SyncLds), stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity);
+        return;
+    }
     hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
 }

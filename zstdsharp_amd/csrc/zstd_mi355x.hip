@@ -29,7 +29,7 @@ void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFra
                        u8* walkWs, hipStream_t stream);
 void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream);
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
-                            u8* slowFlags, hipStream_t stream);
+                            u8* slowFlags, u32 mode, hipStream_t stream);
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
                              const u8* litScratch, hipStream_t stream);
 }
@@ -109,6 +109,7 @@ struct ZSTD_DCtx_s {
     StageTimer timer;
     // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
     std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
+    u32 litDecoder = 0;         // 0 auto, 1 serial (4 lanes per frame), 2 self-synchronising (256 lanes per frame)
 };
 
 
@@ -473,7 +474,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     if (nFrames == 0) { d->timer.finish(); return 0; }
     if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
     (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
-    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, s);     d->timer.mark("decode_literals", s);
+    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, d->litDecoder, s);     d->timer.mark("decode_literals", s);
     launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, s);   d->timer.mark("decode_sequences", s);
     u32 err = 0;
     if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
@@ -664,6 +665,7 @@ size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kEr
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* c, unsigned chunks) { if (!c || chunks == 0 || chunks > (1u << 20)) return ZERR(kErrParameterOutOfBound); c->passChunks = chunks; return 0; }
 size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* c, int en) { if (!c) return ZERR(kErrGeneric); c->timer.enabled = en != 0; return 0; }
 size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* d, int en) { if (!d) return ZERR(kErrGeneric); d->timer.enabled = en != 0; return 0; }
