@@ -345,3 +345,46 @@ def test_levels_buy_ratio(gpu_lib, oracle):
             ref = len(oracle.compress(data, level, 0, 65536))
             assert sizes[(kind, level)] <= ref * slack + 64, (kind, level, sizes[(kind, level)], ref)
     print("level sizes", sizes)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# frames without a content size (what the reference's CompressionStream writes when no size is pledged,
+# U/ZstdCompress.cs:4817-4929 with contentSizeFlag effectively off): decoded into bound-sized slots, then compacted
+# ---------------------------------------------------------------------------------------------------------------
+def _strip_content_size(frame: bytes, content_len: int) -> bytes:
+    """Rewrite ONE frame's header so that it carries a window descriptor instead of a content size."""
+    assert frame[:4] == b"\x28\xb5\x2f\xfd"
+    fhd = frame[4]
+    single, fcs_id, chk, did = (fhd >> 5) & 1, fhd >> 6, fhd & 4, fhd & 3
+    assert did == 0
+    old = 5 + (0 if single else 1) + [1 if single else 0, 2, 4, 8][fcs_id]
+    wlog = max(10, (max(content_len, 1) - 1).bit_length())
+    return frame[:4] + bytes([chk, (wlog - 10) << 3]) + frame[old:]
+
+
+def test_frames_without_content_size(gpu_lib, oracle, forced_decoder):
+    d = forced_decoder
+    blobs, want = [], b""
+    for kind, n in (("text", 200001), ("zipf", 65536), ("runs", 300), ("mixed", 400000), ("rand", 1000)):
+        data = datagen.gen(kind, n, n)
+        sized = oracle.compress(data, 1, 1 if kind == "mixed" else 0, 0)          # one (multi-block) frame, with checksum once
+        unsized = _strip_content_size(sized, n)
+        assert oracle.decompress(unsized, n) == data                               # the rewritten frame is valid zstd
+        assert gpu_lib.ZSTD_getFrameContentSize(unsized, len(unsized)) == (1 << 64) - 1      # ZSTD_CONTENTSIZE_UNKNOWN
+        bound = gpu_lib.ZSTD_decompressBound(unsized, len(unsized))
+        assert n <= bound < (1 << 62)
+        # (Unwrap(src) alone insists on bound == size, as S/Decompressor.cs:56-72 does; the dest form returns the size)
+        dest = bytearray(bound)
+        assert d.Unwrap(unsized, dest) == n and bytes(dest[:n]) == data
+        blobs.append(unsized); want += data
+    # several unsized frames and a sized one in one buffer: gaps between the bound-sized slots are closed
+    sized_tail = oracle.compress(b"tail" * 1000, 1, 0, 0)
+    both = b"".join(blobs) + sized_tail
+    dest = bytearray(gpu_lib.ZSTD_decompressBound(both, len(both)))
+    got = d.Unwrap(both, dest)
+    assert bytes(dest[:got]) == want + b"tail" * 1000
+    # and through the streaming adapter
+    import io
+    from zstdsharp_amd.streams import DecompressionStream
+    with DecompressionStream(io.BytesIO(b"".join(blobs)), 1000) as ds:
+        assert ds.ReadToEnd(7777) == want

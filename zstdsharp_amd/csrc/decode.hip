@@ -59,7 +59,7 @@ __device__ inline FrameHeader parse_frame_header(const u8* p, u64 avail)
 __global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize, FrameDesc* __restrict__ frames, u32 maxFrames, u32* __restrict__ status)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    u64 pos = 0, dstOff = 0; u32 n = 0, err = 0;
+    u64 pos = 0, dstOff = 0; u32 n = 0, err = 0, nUnsized = 0;
     while (srcSize - pos >= 5) {            // ZSTD_decompressMultiFrame loop condition (U/ZstdDecompress.cs:1228)
         const u8* p = src + pos; const u64 avail = srcSize - pos;
         const u32 magic = readLE32(p);
@@ -72,8 +72,7 @@ __global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize
         const FrameHeader h = parse_frame_header(p, avail);
         if (h.err) { err = (h.err == kErrPrefixUnknown && n > 0) ? kErrSrcSizeWrong : h.err; break; }
         if (h.dictID) { err = kErrDictionaryWrong; break; }
-        if (h.contentSize == ~0ull) { err = kErrFrameParameterUnsupported; break; }   // GPU path needs sized frames
-        u64 q = pos + h.headerSize;
+        u64 q = pos + h.headerSize; u64 nbBlocks = 0;
         for (;;) {
             if (srcSize - q < 3) { err = kErrSrcSizeWrong; break; }
             const u32 bh = readLE24(src + q);
@@ -81,18 +80,21 @@ __global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize
             if (type == 3) { err = kErrCorruption; break; }
             if (type == 1) cSize = 1;
             if (3 + (u64)cSize > srcSize - q) { err = kErrSrcSizeWrong; break; }
-            q += 3 + cSize;
+            q += 3 + cSize; nbBlocks++;
             if (last) break;
         }
         if (err) break;
         if (h.checksum) { if (srcSize - q < 4) { err = kErrSrcSizeWrong; break; } q += 4; }
-        if (n >= maxFrames || (q - pos) > 0xFFFFFFFFull || h.contentSize > 0xFFFFFFFFull) { err = kErrMemoryAllocation; break; }
-        FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.srcSize = (u32)(q - pos); f.dstSize = (u32)h.contentSize;
-        frames[n++] = f;
-        dstOff += h.contentSize; pos = q;
+        // a frame without a content size gets the bound ZSTD_findFrameSizeInfo gives it: nbBlocks x min(window, 128 KiB)
+        const bool unsizedF = h.contentSize == ~0ull;
+        const u64 content = unsizedF ? nbBlocks * (h.windowSize < (1u << 17) ? h.windowSize : (u64)(1u << 17)) : h.contentSize;
+        if (n >= maxFrames || (q - pos) > 0xFFFFFFFFull || content > 0xFFFFFFFFull) { err = kErrMemoryAllocation; break; }
+        FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.srcSize = (u32)(q - pos); f.dstSize = (u32)content; f.unsized = unsizedF; f.pad = 0;
+        frames[n++] = f; nUnsized += unsizedF;
+        dstOff += content; pos = q;
     }
     if (!err && pos != srcSize) err = kErrSrcSizeWrong;     // trailing garbage (U/ZstdDecompress.cs:1309-1312)
-    status[0] = n; status[1] = err; status[2] = (u32)dstOff; status[3] = (u32)(dstOff >> 32);
+    status[0] = n; status[1] = err; status[2] = (u32)dstOff; status[3] = (u32)(dstOff >> 32); status[5] = nUnsized;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -959,7 +961,7 @@ __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | 
 // its own match when the match source lies entirely in output produced before this batch; the remaining matches
 // (near, overlapping or long) run in sequence order, 64 lanes per match.
 __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out,
-                                      const u8* __restrict__ litIn, const u32 lane)
+                                      const u8* __restrict__ litIn, const u32 lane, u32* actualOut)
 {
 #define FAIL(code) return (code)
 #ifdef ZMI_LZ_STAMPS
@@ -1199,14 +1201,15 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
 #ifdef ZMI_LZ_STAMPS
     if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_seqStamps[i], stampAcc[i]);
 #endif
-    if (op != fd.dstSize) FAIL(kErrCorruption);           // regenerated size must equal the header's FCS (U/ZstdDecompress.cs:1177-1184)
+    if (!fd.unsized && op != fd.dstSize) FAIL(kErrCorruption);       // regenerated size must equal the header's FCS (U/ZstdDecompress.cs:1177-1184)
+    *actualOut = op;
     if (h.checksum) {
         // XXH64 of the regenerated frame: accumulators on lanes 0..3 (U/ZstdDecompress.cs:1186-1208)
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
         auto rotl = [](u64 x, int r) { return (x << r) | (x >> (64 - r)); };
         auto rnd = [&](u64 acc, u64 in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
-        const u32 n = fd.dstSize, stripes = n >> 5, j = lane & 3;
+        const u32 n = op, stripes = n >> 5, j = lane & 3;
         u64 v = j == 0 ? P1 + P2 : j == 1 ? P2 : j == 2 ? 0 : 0 - P1;
         if (lane < 4) for (u32 i = 0; i < stripes; i++) v = rnd(v, readLE64(out + 32 * i + 8 * j));
         const u64 v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
@@ -1234,15 +1237,17 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
 
 __global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restrict__ src, u64 srcSize, u8* __restrict__ dst, u64 dstCapacity,
                                                               const FrameDesc* __restrict__ frames, u32 nFrames, u32* __restrict__ frameErr,
-                                                              const u8* __restrict__ litScratch)
+                                                              const u8* __restrict__ litScratch, u32* __restrict__ frameActual)
 {
     __shared__ SeqLds L;
     const u32 f = blockIdx.x, lane = threadIdx.x;
     if (f >= nFrames) return;
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane);
+    u32 actual = 0;
+    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane, &actual);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
+    if (frameActual && lane == 0) frameActual[f] = err ? 0u : actual;      // only asked for when some frame carries no content size
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1380,7 +1385,7 @@ __global__ __launch_bounds__(256) void walk_emit_kernel(const u8* __restrict__ s
         u64 next = 0; u32 content = 0;
         const u32 st = chain_step(src, srcSize, pos, &next, &content);
         if (st == 2) return;                                   // cannot happen: the chain was validated by walk_segments
-        if (st == 0) { FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.srcSize = (u32)(next - pos); f.dstSize = content; frames[idx++] = f; dstOff += content; }
+        if (st == 0) { FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.srcSize = (u32)(next - pos); f.dstSize = content; f.unsized = 0; f.pad = 0; frames[idx++] = f; dstOff += content; }
         pos = next;
     }
 }
@@ -1674,9 +1679,9 @@ void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames,
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
 }
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, hipStream_t stream)
+                             const u8* litScratch, u32* frameActual, hipStream_t stream)
 {
-    hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch);
+    hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch, frameActual);
 }
 
 #ifdef ZMI_LZ_STAMPS

@@ -60,7 +60,9 @@ struct FrameDesc {      // one per frame found by the frame walk (U/ZstdDecompre
     u64 srcOff;         // offset of the frame in the compressed input
     u64 dstOff;         // offset of its content in the output
     u32 srcSize;        // compressed frame size
-    u32 dstSize;        // content size (frames with unknown content size are not dispatched to the GPU path)
+    u32 dstSize;        // content size; for a frame without one (unsized = 1) the bound nbBlocks x blockSizeMax (U/ZstdDecompress.cs:877-951)
+    u32 unsized;        // 1 = the header carries no content size: the decoder reports the regenerated size instead of checking it
+    u32 pad;
 };
 
 // error codes: U/ZSTD_ErrorCode.cs

@@ -31,7 +31,7 @@ void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
                             u8* slowFlags, u32 mode, hipStream_t stream);
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, hipStream_t stream);
+                             const u8* litScratch, u32* frameActual, hipStream_t stream);
 }
 
 using namespace zmi;
@@ -105,7 +105,7 @@ struct ZSTD_DCtx_s {
     int windowLogMax = 27;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf frames, status, frameErr, scratch, walkWs, slowFlags, stageSrc, stageDst;
+    DevBuf frames, status, frameErr, scratch, walkWs, slowFlags, stageSrc, stageDst, actual;
     StageTimer timer;
     // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
     std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
@@ -331,7 +331,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release();
+        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->actual.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -462,9 +462,10 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     u32 st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
     if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-    if (!st[4]) {       // the segment links did not close: take the exact serial walk (it also yields the reference's error code)
+    const bool serialWalk = !st[4];
+    if (serialWalk) {   // the segment links did not close: take the exact serial walk (it also yields the reference's error code)
         launch_frame_walk_serial(d_src, srcSize, frames, maxFrames, status, s);
-        if (hipMemcpyAsync(st, status, 4 * sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
         if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     }
     if (st[1]) return ZERR(st[1]);
@@ -475,12 +476,31 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
     (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
     launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, d->litDecoder, s);     d->timer.mark("decode_literals", s);
-    launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, s);   d->timer.mark("decode_sequences", s);
+    // frames without a content size (st[5] of them; only the serial walk lets them through) are decoded into bound-sized
+    // slots, report their regenerated size, and are then moved down to close the gaps
+    const u32 nUnsized = serialWalk ? st[5] : 0u;
+    if (nUnsized && !d->actual.ensure((size_t)nFrames * sizeof(u32))) return ZERR(kErrMemoryAllocation);
+    launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, nUnsized ? (u32*)d->actual.p : nullptr, s);   d->timer.mark("decode_sequences", s);
     u32 err = 0;
     if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     d->timer.finish();
     if (err) return ZERR(err);
+    if (nUnsized) {
+        std::vector<FrameDesc> hf(nFrames); std::vector<u32> ha(nFrames);
+        if (hipMemcpy(hf.data(), frames, (size_t)nFrames * sizeof(FrameDesc), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipMemcpy(ha.data(), d->actual.p, (size_t)nFrames * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+        u64 at = 0;
+        for (u32 f = 0; f < nFrames; ++f) {
+            if (at != hf[f].dstOff && ha[f]) {      // overlapping move: through the literal scratch (it is as large as the output)
+                if (hipMemcpyAsync(d->scratch.p, d_dst + hf[f].dstOff, ha[f], hipMemcpyDeviceToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+                if (hipMemcpyAsync(d_dst + at, d->scratch.p, ha[f], hipMemcpyDeviceToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+            }
+            at += ha[f];
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        return (size_t)at;
+    }
     return (size_t)total;
 }
 
