@@ -254,7 +254,7 @@ __device__ __forceinline__ SeqSym seq_entry(u32 sym, u32 nextState, u32 tableLog
 //                                (prefix count of kept cells, then a binary search in the cumulative counts);
 //   nextState = symbolNext++  -> cells are taken 64 at a time in index order; within a group the lanes that hold the
 //                                same symbol are ranked with a ballot, and the per-symbol counter lives in that symbol's lane.
-__device__ inline void build_seq_dtable_wave(SeqSym* t, u16* cum, const s16* norm, u32 maxSV, u32 tableLog, int kind, u32 lane)
+__device__ __forceinline__ void build_seq_dtable_wave(SeqSym* t, u16* cum, const s16* norm, u32 maxSV, u32 tableLog, int kind, u32 lane)
 {
     const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
     const int nrm = lane <= maxSV ? (int)norm[lane] : 0;
@@ -303,7 +303,7 @@ __device__ inline void build_seq_dtable_wave(SeqSym* t, u16* cum, const s16* nor
 
 // ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), whole wave; only the NCount header is parsed by one lane.
 // Returns bytes consumed or 0xFFFFFFFF on error (uniform).
-__device__ inline u32 set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32* validPtr, u32 type, u32 max, u32 maxLog,
+__device__ __forceinline__ u32 set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32* validPtr, u32 type, u32 max, u32 maxLog,
                                     const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax, u32 lane)
 {
     switch (type) {
@@ -1422,6 +1422,9 @@ void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32
 // =====================================================================================================================
 constexpr u32 kStageBytes = 16384;
 struct SyncLds {
+    // one compressed stream per wave, staged with coalesced loads: the spans' containers are then refilled from LDS (per-lane
+    // 8-byte global loads cost one cache-line request per lane per refill, which is what bounds the serial decoder too).
+    u8  stage[4][kStageBytes];  // first member: 16-byte aligned
     u16 huf[4096];              // X1 table: byte | nbBits << 8.  Before it is filled its storage holds the FSE scratch.
     u8  weights[256];
     u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded
@@ -1429,123 +1432,172 @@ struct SyncLds {
     u32 classFirst[14];         // index into sorted[] of the first symbol of class w
     u32 meta[4];
     u32 err;
-    // one compressed stream per wave, staged with coalesced loads: the spans' containers are then refilled from LDS (per-lane
-    // 8-byte global loads cost one cache-line request per lane per refill, which is what bounded the serial decoder too).
-    // Bytes [0, 8) are zero: reads below the start of the stream.
-    u8  stage[4][kStageBytes];
 };
 
-// Decode the span (lo, p] of a stream from a start position p (codeword boundary or guess) down to the first boundary at
-// or below lo.  `sb` points at stream byte 0 (LDS stage + 8, or global memory when the stream did not fit the stage;
-// then `size` bounds the reads).  WRITE: symbols go to out[0..), 16 per store.
-template <bool WRITE, bool STAGED>
-__device__ __forceinline__ void huf_span(const u16* __restrict__ table, const u32 tableLog, const u8* __restrict__ sb, const s32 size,
-                                         s32 p, const s32 lo, u8* __restrict__ out, s32& endOut, u32& cntOut)
-{
-    u32 cnt = 0;
-    if (p > lo) {
-        s32 ptr = ((p + 7) >> 3) - 8;                       // container = stream bytes [ptr, ptr + 8), ptr >= -7
-        u32 consumed = (u32)(8 * (ptr + 8) - p);            // bits of the container already used (0..7)
-        auto load8 = [&](s32 idx) -> u64 {
-            if (STAGED) return readLE64(sb + idx);          // the stage has 8 zero bytes below the stream
-            if (idx >= 0 && idx + 8 <= size) return readLE64(sb + idx);
-            u64 v = 0;
-            for (s32 i = 0; i < 8; i++) { const s32 k = idx + i; if (k >= 0 && k < size) v |= (u64)sb[k] << (8 * i); }
-            return v;
-        };
-        const u32 sh = 32 - tableLog;
-        bool more = true;
-        while (more) {
-            u32 w4[4] = { 0, 0, 0, 0 }; u32 k = 0;
-#pragma unroll
-            for (u32 g = 0; g < 4; ++g) {
-                if (more) {
-                    const u64 cont = load8(ptr);
-                    const u32 limit = (u32)(8 * (ptr + 8) - lo);        // the span ends once consumed >= limit
-#pragma unroll
-                    for (u32 j = 0; j < 4; ++j) {
-                        if (more) {
-                            const u32 e = table[(u32)((cont << consumed) >> 32) >> sh];
-                            consumed += e >> 8; ++k;
-                            if (WRITE) w4[g] |= (e & 0xFFu) << (8 * j);
-                            more = consumed < limit;
-                        }
-                    }
-                    ptr -= (s32)(consumed >> 3); consumed &= 7;
-                }
-            }
-            if (WRITE) {
-                if (k == 16) { u32u* o = (u32u*)(out + cnt); o[0] = w4[0]; o[1] = w4[1]; o[2] = w4[2]; o[3] = w4[3]; }
-                else for (u32 j = 0; j < k; ++j) out[cnt + j] = (u8)(w4[j >> 2] >> (8 * (j & 3)));
-            }
-            cnt += k;
-        }
-        p = 8 * (ptr + 8) - (s32)consumed;
+// One decode chain over the span (lo, p] of a stream: from a start position p (a codeword boundary or a guess) down to the
+// first boundary at or below lo.  `sb` points at stream byte 0 (LDS stage + 8, or global memory when the stream did not
+// fit the stage; then `size` bounds the reads).  The 4-symbol group is branch-free (a finished chain keeps looking up
+// but stops advancing), so that two chains of a lane can be interleaved instruction by instruction.
+template <bool STAGED>
+struct SpanChain {
+    s32 ptr; u32 consumed; u32 more; s32 lo; u32 cnt;
+    __device__ __forceinline__ void init(s32 p, s32 lo_)
+    {
+        lo = lo_; cnt = 0; more = p > lo_;
+        ptr = ((p + 7) >> 3) - 8;                           // container = stream bytes [ptr, ptr + 8), ptr >= -7 while the chain runs
+        consumed = (u32)(8 * (ptr + 8) - p);                // bits of the container already used (0..7)
     }
-    endOut = p; cntOut = cnt;
+    __device__ __forceinline__ s32 pos() const { return 8 * (ptr + 8) - (s32)consumed; }
+    __device__ __forceinline__ u64 load8(const u8* __restrict__ sb, s32 size) const
+    {
+        const s32 idx = more ? ptr : 0;
+        if (STAGED) {
+            // LDS: three aligned dwords + v_alignbyte (an unaligned 8-byte LDS read is split into byte reads by the compiler).
+            // sb is 16-byte aligned and the stage has 16 zero bytes below the stream and 8 of slack above it.
+            const u32 a = (u32)(idx + 16);
+            const u32* w32 = reinterpret_cast<const u32*>(sb - 16) + (a >> 2);
+            const u32 d0 = w32[0], d1 = w32[1], d2 = w32[2], shb = a & 3;
+            return (u64)__builtin_amdgcn_alignbyte(d1, d0, shb) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, shb) << 32);
+        }
+        if (idx >= 0 && idx + 8 <= size) return readLE64(sb + idx);
+        u64 v = 0;
+        for (s32 i = 0; i < 8; i++) { const s32 k = idx + i; if (k >= 0 && k < size) v |= (u64)sb[k] << (8 * i); }
+        return v;
+    }
+};
+
+// up to 4 symbols of chain A and of chain B, interleaved; returns the packed symbols (valid ones counted in kA / kB)
+template <bool STAGED, bool WRITE>
+__device__ __forceinline__ void span_group2(const u16* __restrict__ table, const u32 sh, const u8* __restrict__ sb, const s32 size,
+                                            SpanChain<STAGED>& A, SpanChain<STAGED>& B, u32& wA, u32& wB, u32& kA, u32& kB)
+{
+    const u64 cA = A.load8(sb, size), cB = B.load8(sb, size);
+    const u32 limA = (u32)(8 * (A.ptr + 8) - A.lo), limB = (u32)(8 * (B.ptr + 8) - B.lo);
+    u32 conA = A.consumed, conB = B.consumed, mA = A.more, mB = B.more;
+    wA = 0; wB = 0; kA = 0; kB = 0;
+#pragma unroll
+    for (u32 j = 0; j < 4; ++j) {
+        const u32 eA = table[(u32)((cA << (conA & 63)) >> 32) >> sh];
+        const u32 eB = table[(u32)((cB << (conB & 63)) >> 32) >> sh];
+        conA += mA ? (eA >> 8) : 0u; conB += mB ? (eB >> 8) : 0u;
+        kA += mA; kB += mB;
+        if (WRITE) { wA |= (mA ? (eA & 0xFFu) : 0u) << (8 * j); wB |= (mB ? (eB & 0xFFu) : 0u) << (8 * j); }
+        mA = mA & (conA < limA); mB = mB & (conB < limB);
+    }
+    A.ptr -= (s32)(conA >> 3); A.consumed = conA & 7; A.more = mA; A.cnt += kA;
+    B.ptr -= (s32)(conB >> 3); B.consumed = conB & 7; B.more = mB; B.cnt += kB;
 }
 
-// one stream on one wave; true iff it decodes to exactly n symbols and is consumed to its first bit
+// run both chains of a lane to the end of their spans; WRITE: symbols to outA / outB, 16 per store
+template <bool STAGED, bool WRITE>
+__device__ __forceinline__ void span_run2(const u16* __restrict__ table, const u32 tableLog, const u8* __restrict__ sb, const s32 size,
+                                          SpanChain<STAGED>& A, SpanChain<STAGED>& B, u8* __restrict__ outA, u8* __restrict__ outB)
+{
+    const u32 sh = 32 - tableLog;
+    while (A.more | B.more) {
+        u32 wa[4], wb[4], ka[4], kb[4];
+#pragma unroll
+        for (u32 g = 0; g < 4; ++g) span_group2<STAGED, WRITE>(table, sh, sb, size, A, B, wa[g], wb[g], ka[g], kb[g]);
+        if (WRITE) {
+            const u32 nA = ka[0] + ka[1] + ka[2] + ka[3], nB = kb[0] + kb[1] + kb[2] + kb[3];
+            if (nA == 16) { u32u* o = (u32u*)outA; o[0] = wa[0]; o[1] = wa[1]; o[2] = wa[2]; o[3] = wa[3]; }
+            else { u32 t = 0; for (u32 g = 0; g < 4; ++g) for (u32 j = 0; j < 4; ++j) if (j < ka[g]) outA[t++] = (u8)(wa[g] >> (8 * j)); }
+            if (nB == 16) { u32u* o = (u32u*)outB; o[0] = wb[0]; o[1] = wb[1]; o[2] = wb[2]; o[3] = wb[3]; }
+            else { u32 t = 0; for (u32 g = 0; g < 4; ++g) for (u32 j = 0; j < 4; ++j) if (j < kb[g]) outB[t++] = (u8)(wb[g] >> (8 * j)); }
+            outA += nA; outB += nB;
+        }
+    }
+}
+
+// one stream on one wave; true iff it decodes to exactly n symbols and is consumed to its first bit.  The stream's bits
+// are cut into 128 spans, two ADJACENT ones per lane (two independent lookup chains per lane hide each other's LDS
+// latency).  Every span first decodes a short run-in above its upper boundary to fall into step, so its first guess of its
+// own start is almost always the true one; starts are then corrected from the span above until none changes.
 template <bool STAGED>
 __device__ __forceinline__ bool huf_stream_passes(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ sb, u32 srcSize, u32 last,
                                                   u8* __restrict__ out, u32 n, u32 lane)
 {
     const s32 P0 = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-    s32 span = (P0 + 63) / 64; if (span < 128) span = 128;              // >= 10 codewords per span
-    const s32 hi = P0 - (s32)lane * span;                                // my upper boundary (first guess of my start)
-    const s32 lo = hi - span > 0 ? hi - span : 0;
-    s32 start = hi, end = hi; u32 cnt = 0;
-    bool dirty = true;
+    s32 span = (P0 + 127) / 128; if (span < 128) span = 128;            // >= 10 codewords per span
+    const s32 kRunIn = 256;                                              // bits decoded above a span to synchronise (~40 codewords)
+    const s32 hiA = P0 - (s32)(2 * lane) * span, hiB = hiA - span;       // upper boundaries of my two spans
+    const s32 loA = hiB > 0 ? hiB : 0, loB = hiB - span > 0 ? hiB - span : 0;
+    SpanChain<STAGED> A, B;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long t0 = __builtin_amdgcn_s_memtime(); u32 nPass = 0;
 #endif
-    for (u32 pass = 0; pass < 66; ++pass) {
-        if (dirty) huf_span<false, STAGED>(table, tableLog, sb, (s32)srcSize, start, lo, nullptr, end, cnt);
-        s32 ns = __shfl_up(end, 1);
-        if (lane == 0) ns = P0;
-        dirty = ns != start;
-        start = ns;
+    // run-in: first boundary at or below my upper boundary, reached from kRunIn bits above it (lane 0's span A starts exactly)
+    {
+        const s32 gA = hiA + kRunIn < P0 ? hiA + kRunIn : P0, gB = hiB + kRunIn < P0 ? hiB + kRunIn : P0;
+        A.init(gA, hiA > 0 ? hiA : 0); B.init(gB, hiB > 0 ? hiB : 0);
+        if (hiA <= 0) A.init(hiA, hiA);
+        if (hiB <= 0) B.init(hiB, hiB);
+        span_run2<STAGED, false>(table, tableLog, sb, (s32)srcSize, A, B, nullptr, nullptr);
+    }
+    s32 startA = lane == 0 ? P0 : A.pos(), startB = B.pos();
+    s32 endA = startA, endB = startB; u32 cntA = 0, cntB = 0;
+    bool dirtyA = true, dirtyB = true;
+    for (u32 pass = 0; pass < 130; ++pass) {
+        // (a clean chain is re-initialised at its own end: nothing to do)
+        A.init(dirtyA ? startA : endA, dirtyA ? loA : endA); B.init(dirtyB ? startB : endB, dirtyB ? loB : endB);
+        span_run2<STAGED, false>(table, tableLog, sb, (s32)srcSize, A, B, nullptr, nullptr);
+        if (dirtyA) { endA = A.pos(); cntA = A.cnt; }
+        if (dirtyB) { endB = B.pos(); cntB = B.cnt; }
+        s32 nsA = __shfl_up(endB, 1);
+        if (lane == 0) nsA = P0;
+        const s32 nsB = endA;
+        dirtyA = nsA != startA; dirtyB = nsB != startB;
+        startA = nsA; startB = nsB;
 #ifdef ZMI_LZ_STAMPS
         ++nPass;
 #endif
-        if (!ballot(dirty)) break;
+        if (!ballot(dirtyA | dirtyB)) break;
     }
 #ifdef ZMI_LZ_STAMPS
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-    const u32 incl = wave_scan_incl(cnt);
+    const u32 cnt2 = cntA + cntB;
+    const u32 incl = wave_scan_incl(cnt2);
     const u32 total = read_lane(incl, 63);
-    const s32 finalEnd = (s32)read_lane((u32)end, 63);
+    const s32 finalEnd = (s32)read_lane((u32)endB, 63);
     if (total != n || finalEnd != 0) return false;
-    s32 e2; u32 c2;
-    huf_span<true, STAGED>(table, tableLog, sb, (s32)srcSize, start, lo, out + (incl - cnt), e2, c2);
+    A.init(startA, loA); B.init(startB, loB);
+    span_run2<STAGED, true>(table, tableLog, sb, (s32)srcSize, A, B, out + (incl - cnt2), out + (incl - cnt2) + cntA);
 #ifdef ZMI_LZ_STAMPS
     if (lane == 0) { atomicAdd(&g_seqStamps[8], (unsigned long long)nPass); atomicAdd(&g_seqStamps[9], 1ull); atomicAdd(&g_seqStamps[10], t1 - t0); atomicAdd(&g_seqStamps[11], __builtin_amdgcn_s_memtime() - t1); }
 #endif
     return true;
 }
-__device__ bool huf_decode_stream_sync(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ src, u32 srcSize,
+__device__ __forceinline__ bool huf_decode_stream_sync(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ src, u32 srcSize,
                                        u8* __restrict__ out, u32 n, u32 lane, u8* __restrict__ stage)
 {
     if (srcSize < 1) return false;
     const u32 last = uniform((u32)src[srcSize - 1]);
     if (!last) return false;
-    if (srcSize + 8 <= kStageBytes) {
-        // stage: [0,8) zeros, then the stream; 16 bytes per lane per step
-        if (lane < 2) reinterpret_cast<u32*>(stage)[lane] = 0;
-        for (u32 i = lane * 16; i < srcSize; i += 1024) {
-            if (i + 16 <= srcSize) { const u64 a = readLE64(src + i), b = readLE64(src + i + 8); *(u64u*)(stage + 8 + i) = a; *(u64u*)(stage + 16 + i) = b; }
-            else for (u32 k = i; k < srcSize; ++k) stage[8 + k] = src[k];
+    if (srcSize + 32 <= kStageBytes) {
+        // stage: 16 zero bytes, then the stream (16-byte aligned), then zeros up to the next 16-byte boundary + 16
+        uint4* st4 = reinterpret_cast<uint4*>(stage);
+        if (lane == 0) st4[0] = make_uint4(0, 0, 0, 0);
+        const u32 pieces = (srcSize + 15) / 16 + 1;
+        for (u32 i = lane; i < pieces; i += 64) {
+            const u32 o = 16 * i; uint4 v = make_uint4(0, 0, 0, 0);
+            if (o + 16 <= srcSize) { const u64 a = readLE64(src + o), b = readLE64(src + o + 8); v = make_uint4((u32)a, (u32)(a >> 32), (u32)b, (u32)(b >> 32)); }
+            else if (o < srcSize) {
+                u32 w[4] = { 0, 0, 0, 0 };
+                for (u32 k = o; k < srcSize; ++k) w[(k - o) >> 2] |= (u32)src[k] << (8 * ((k - o) & 3));
+                v = make_uint4(w[0], w[1], w[2], w[3]);
+            }
+            st4[1 + i] = v;
         }
         wave_lds_sync();
-        const bool ok = huf_stream_passes<true>(table, tableLog, stage + 8, srcSize, last, out, n, lane);
+        const bool ok = huf_stream_passes<true>(table, tableLog, stage + 16, srcSize, last, out, n, lane);
         wave_lds_sync();
         return ok;
     }
     return huf_stream_passes<false>(table, tableLog, src, srcSize, last, out, n, lane);
 }
 
-__device__ u32 sync_decode_literals(SyncLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 tid)
+__device__ __forceinline__ u32 sync_decode_literals(SyncLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 tid)
 {
     const u32 lane = tid & 63, wave = tid >> 6;
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
@@ -1663,12 +1715,12 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
 }
 
 // Two literal decoders.  The serial one (4 lanes per frame) has the fewest instructions per symbol and wins once there
-// are enough frames to fill the chip (one round = 8192 frames: 1.0-1.7 ms for 16..8192 frames, 3.5 ms for 16384); the
-// self-synchronising one (256 lanes per frame) takes 0.18 ms up to 256 frames and 0.34 ms per 1000 frames beyond.  mode: 0 = choose by frame count, 1 = serial, 2 = self-synchronising.
+// are enough frames to fill the chip (one round = 8192 frames: 1.0-1.7 ms for 16..8192 frames, 3.3 ms for 16384); the
+// self-synchronising one (256 lanes per frame) takes 0.15 ms up to 256 frames and 0.25 ms per 1000 frames beyond.  mode: 0 = choose by frame count, 1 = serial, 2 = self-synchronising.
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
                             u8* slowFlags, u32 mode, hipStream_t stream)
 {
-    const bool sync = mode == 2 || (mode == 0 && nFrames <= 4096);      // measured crossover ~4400 frames (tools/lit_decoder_crossover.py)
+    const bool sync = mode == 2 || (mode == 0 && nFrames <= 6144);      // measured crossover ~6100 frames (tools/lit_decoder_crossover.py)
     if (sync) {
         static bool attrSet = false;
         if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_literals_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SyncLds)); attrSet = true; }

@@ -121,7 +121,7 @@ __device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w,
     u32 l = x ? (ctz64(x) >> 3) : 8;
     if (!x) {
         while (l < kLenCap) {
-            x = readLE64(L.in + p + l) ^ readLE64(L.in + cpos + l);
+            x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
             if (x) { l += ctz64(x) >> 3; break; }
             l += 8;
         }
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         u32 e = p + kLenCap;
         for (;;) {
             const u32 pos = e + 8 * lane;              // reads past n land in the table region: harmless, clamped below
-            const u64 x = readLE64(L.in + pos) ^ readLE64(L.in + pos - off);
+            const u64 x = lds_load8(L.in, pos) ^ lds_load8(L.in, pos - off);
             const u64 bad = ballot(x != 0 || pos + 8 > n);
             if (bad == 0) { e += 512; continue; }
             const u32 fl = ctz64(bad);
