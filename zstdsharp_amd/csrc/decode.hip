@@ -169,7 +169,6 @@ struct SeqLds {
     u16 symbolNext[64];
     u32 llLog, mlLog, ofLog;
     u32 llValid, mlValid, ofValid;
-    u32 bLL[64], bML[64], bOFF[64];     // one batch of decoded sequences (lane 0 decodes, 64 lanes execute)
 };
 
 __constant__ u8  dLL_bits[36] = { 0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,2,2,3,3,4,6,7,8,9,10,11,12,13,14,15,16 };
@@ -855,44 +854,6 @@ __device__ __forceinline__ void wave_match_copy(u8* d, u32 offset, u32 n, u32 la
     for (u32 i = lane; i < n; i += 64) d[i] = s0[i % offset];
 }
 
-// Backward bit reader for the sequence section, used by ONE lane (U/Bitstream.cs:172-426).  Same container scheme as
-// the literal streams: `cont` holds 64 stream bits, re-based by whole bytes from `raw`, the 8 bytes below it, which
-// are fetched one re-base ahead.  Bytes outside the stream read as zero (the reference's overflow behaviour).
-struct SeqBits {
-    const u8* s; s32 size, ptr, lp; u64 cont, raw; u32 consumed;
-    __device__ __forceinline__ u64 load8z(s32 idx) const      // slow, exact: zeros outside [0, size)
-    {
-        if (idx >= 0 && idx + 8 <= size) return readLE64(s + idx);
-        u64 v = 0;
-        for (s32 i = 0; i < 8; i++) { const s32 k = idx + i; if (k >= 0 && k < size) v |= (u64)s[k] << (8 * i); }
-        return v;
-    }
-    __device__ __forceinline__ bool init(const u8* p, s32 n)
-    {
-        s = p; size = n; ptr = 0; lp = 0; cont = 0; raw = 0; consumed = 0;
-        if (n < 1) return false;
-        const u32 last = p[n - 1];
-        if (!last) return false;
-        const s32 remaining = (n - 1) * 8 + (s32)highbit32(last);
-        ptr = n - 8; cont = load8z(ptr); lp = ptr - 8; raw = load8z(lp);
-        consumed = 64u - (u32)(remaining - 8 * ptr);
-        return true;
-    }
-    // afterwards consumed <= 7: up to 57 bits can be read.  Branch-free for streams of >= 16 bytes so that the prefetch
-    // load is waited for only where `raw` is next used (one sequence later).
-    __device__ __forceinline__ void rebase()
-    {
-        const u32 k = consumed >> 3;
-        const u64 lower = size >= 16 ? (lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0)) : raw;
-        cont = k == 0 ? cont : (k >= 8 ? lower : ((cont << (8 * k)) | (lower >> (64 - 8 * k))));
-        ptr -= (s32)k; consumed -= 8 * k; lp = ptr - 8;
-        if (size >= 16) raw = readLE64(s + (lp > 0 ? lp : 0));       // uniform branch (size is fixed per stream)
-        else raw = load8z(lp);
-    }
-    __device__ __forceinline__ u32 read(u32 nb) { const u32 v = nb ? (u32)((cont << consumed) >> (64 - nb)) : 0u; consumed += nb; return v; }
-    __device__ __forceinline__ s32 remaining() const { return 8 * ptr + 64 - (s32)consumed; }
-};
-
 // Wave-uniform reader of the backward sequence bitstream, for the state chain.  The stream is seen as dwords (dword d =
 // stream bytes 4d..4d+3, zero outside the stream); lane l of `winCur` holds dword wbase + l and `winNext` the window 32
 // dwords lower, fetched one rotation ahead.  Bits are taken straight out of the window with two v_readlane and a scalar
@@ -955,11 +916,11 @@ struct SBits {
 __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | ((u64)uniform((u32)(v >> 32)) << 32); }
 
 
-// Sequences of one frame on one wave.  Per block: lane 0 runs the serial state chain (ZSTD_decodeSequence,
-// U/ZstdDecompressBlock.cs:2360-2484) 64 sequences at a time into LDS; then all 64 lanes execute the batch
-// (ZSTD_execSequence, :2187-2262): output positions by prefix sum, every lane copies its own sequence's literals and
-// its own match when the match source lies entirely in output produced before this batch; the remaining matches
-// (near, overlapping or long) run in sequence order, 64 lanes per match.
+// Sequences of one frame on one wave.  Per block, 64 sequences at a time: the FSE state chain (ZSTD_decodeSequence,
+// U/ZstdDecompressBlock.cs:2360-2484) runs wave-uniform on the scalar unit and records states + bit position per
+// sequence; every lane extracts the fields of its own sequence; repcodes are resolved in order; then all 64 lanes execute
+// the batch (ZSTD_execSequence, :2187-2262): output positions by prefix sum, literals (long runs in 16-byte pieces dealt
+// round-robin), matches in dependency rounds.
 __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out,
                                       const u8* __restrict__ litIn, const u32 lane, u32* actualOut)
 {
