@@ -1683,8 +1683,9 @@ void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames,
 {
     const bool sync = mode == 2 || (mode == 0 && nFrames <= 6144);      // measured crossover ~6100 frames (tools/lit_decoder_crossover.py)
     if (sync) {
-        static bool attrSet = false;
-        if (!attrSet) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_literals_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SyncLds)); attrSet = true; }
+        static bool attrSet[64] = {};               // per device
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (!attrSet[dev & 63]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_literals_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SyncLds)); attrSet[dev & 63] = true; }
         hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nFrames), dim3(256), sizeof(SyncLds), stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity);
         return;
     }

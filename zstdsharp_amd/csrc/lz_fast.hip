@@ -379,20 +379,34 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             // of itself: after r rounds the orbit points of index < 4^r are marked, and J^(4^r)(s0) leaving the tile ends it.
             if (s0 != kExit) {
                 for (u32 round = 0; round < kTileLog; ++round) {
+                    // the hops of the thread's four positions are independent chains of LDS reads: written hop-major and
+                    // branch-free so that the four reads of a hop are in flight together; marks come afterwards
+                    u32 a[kPPT][kHop]; bool isSel[kPPT];
 #pragma unroll
                     for (u32 j = 0; j < kPPT; ++j) {
                         const u32 q = j * kTile + tid;
-                        if (has[j]) {
-                            const bool isSel = (L.selMask[q >> 6] >> (q & 63)) & 1ull;
-                            u32 a = cur[q];
+                        isSel[j] = has[j] && ((L.selMask[q >> 6] >> (q & 63)) & 1ull);
+                        a[j][0] = has[j] ? (u32)cur[q] : kExit;
+                    }
 #pragma unroll
-                            for (u32 hop = 1; hop < kHop; ++hop) {
-                                if (a == kExit) break;
-                                if (isSel) atomicOr((unsigned long long*)&L.selMask[a >> 6], (unsigned long long)(1ull << (a & 63)));
-                                a = cur[a];
-                            }
-                            nxt[q] = (u16)a;
+                    for (u32 hop = 1; hop < kHop; ++hop) {
+#pragma unroll
+                        for (u32 j = 0; j < kPPT; ++j) {
+                            const u32 pv = a[j][hop - 1];
+                            const u32 nx = cur[pv != kExit ? pv : 0];
+                            a[j][hop] = pv != kExit ? nx : kExit;
                         }
+                    }
+#pragma unroll
+                    for (u32 j = 0; j < kPPT; ++j) {
+                        if (isSel[j]) {
+#pragma unroll
+                            for (u32 hop = 0; hop + 1 < kHop; ++hop) {
+                                const u32 t = a[j][hop];
+                                if (t != kExit) atomicOr((unsigned long long*)&L.selMask[t >> 6], (unsigned long long)(1ull << (t & 63)));
+                            }
+                        }
+                        if (has[j]) nxt[j * kTile + tid] = (u16)a[j][kHop - 1];
                     }
                     __syncthreads();
                     { u16* t_ = cur; cur = nxt; nxt = t_; }
@@ -544,10 +558,12 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 template <int MODE, int SHORT>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
 {
-    static bool attrSet = false;
-    if (!attrSet) {
+    // (the attribute is per device: a process may hold contexts on several GPUs)
+    static bool attrSet[64] = {};
+    int dev = 0; (void)hipGetDevice(&dev);
+    if (!attrSet[dev & 63]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
-        attrSet = true;
+        attrSet[dev & 63] = true;
     }
     hipLaunchKernelGGL((lz_kernel<MODE, SHORT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta);
 }
