@@ -9,6 +9,8 @@ lib = ffi.load()
 raw = ctypes.CDLL(ffi.LIB_PATH); raw.ZSTDMI_debugReadLzStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 raw.ZSTDMI_debugReadHufStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
 raw.ZSTDMI_debugReadSeqStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+raw.ZSTDMI_debugReadSeqEncStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong), ctypes.c_int]
+enames = ["repcodes", "histograms", "tables (lane 0)", "pack+flush (+batch load)", "state chains"]
 snames = ["other", "state chain", "fields+reps", "literals", "indep matches", "dependent matches"]
 hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
 names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense:init+rounds", "dense:finish+rank"]
@@ -19,7 +21,7 @@ for kind in ("zipf", "text"):
     cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
-    buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1); raw.ZSTDMI_debugReadHufStamps(buf, 1)
+    buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1); raw.ZSTDMI_debugReadHufStamps(buf, 1); raw.ZSTDMI_debugReadSeqEncStamps(buf, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     raw.ZSTDMI_debugReadLzStamps(buf, 1)
     tot = sum(buf[i] for i in range(8)); chunks = n // 65536
@@ -27,6 +29,9 @@ for kind in ("zipf", "text"):
     raw.ZSTDMI_debugReadHufStamps(buf, 1)
     tot = sum(buf[i] for i in range(8))
     print(kind, "huf_build cycles/chunk", tot // chunks, {hnames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)
+    raw.ZSTDMI_debugReadSeqEncStamps(buf, 1)
+    tot = sum(buf[i] for i in range(5))
+    print(kind, "seq_encode cycles/chunk", tot // chunks, {enames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(5)}, flush=True)
     back = torch.empty(n, dtype=torch.uint8, device="cuda")
     cs = lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     d = lib.ZSTD_createDCtx()

@@ -32,6 +32,13 @@ __constant__ s16 cOF_defaultNorm[29] = { 1,1,1,1,1,1,2,2,2,1,1,1,1,1,1,1,1,1,1,1
 __device__ __forceinline__ u32 ll_code(u32 ll) { return ll > 63 ? highbit32(ll) + 19 : cLL_Code[ll]; }
 __device__ __forceinline__ u32 ml_code(u32 ml) { return ml > 127 ? highbit32(ml) + 36 : cML_Code[ml]; }
 
+#ifdef ZMI_LZ_STAMPS
+__device__ unsigned long long g_sencStamps[16];
+#define ZMI_ESTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } while (0)
+#else
+#define ZMI_ESTAMP(i) do { } while (0)
+#endif
+
 struct SeqWaveLds {
     u32 count[3][64];                   // LL, OF, ML code histograms
     u16 llState[512]; u16 mlState[512]; u16 ofState[256];
@@ -104,38 +111,56 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     u8* const slot = slots + (u64)c * kSlotStride;
     u8* const body = slot + m.fhSize + 3;
 
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
     for (u32 i = lane; i < 3 * 64; i += 64) (&W.count[0][0])[i] = 0;
     if (resolveReps) {
         // The match finder stores raw offsets (distance + 3).  Turning them into repcodes is a serial state machine over
         // the sequences — the decoder's history rule (U/ZstdDecompressBlock.cs:2387-2443) run forward — so it lives
         // here: 64 sequences are loaded per step (coalesced), the chain itself runs on scalar values.
-        u32 rep0 = 1, rep1 = 4, rep2 = 8;
+        // Written as a recurrence on the history BEFORE each sequence, the rule needs no serial walk:
+        //   rep0 before k  = offset of sequence k-1, always (every case of the rule leaves the used offset in front);
+        //   rep1 before k  = rep0 before j, j = the latest earlier sequence that was not a plain rep0 hit;
+        //   rep2 before k  = rep1 before j, j = the latest earlier sequence that neither hit rep0 nor swapped with rep1.
+        // "Latest earlier sequence with a property" is a ballot and a count-leading-zeros; the value comes by shuffle.
+        u32 R0 = 1, R1 = 4, R2 = 8;                    // history before the batch (uniform)
         for (u32 b0 = 0; b0 < nbSeq; b0 += 64) {
             const u32 i = b0 + lane;
             Seq s; s.offBase = 4; s.litLength = 0; s.mlBase = 0;
             if (i < nbSeq) s = sq[i];
-            const u32 myOff = s.offBase - 3, myLL = s.litLength;
-            u32 myCode = s.offBase;
             const u32 cnt = nbSeq - b0 < 64 ? nbSeq - b0 : 64;
-            for (u32 k = 0; k < cnt; k++) {
-                const u32 off = read_lane(myOff, k), ll0 = read_lane(myLL, k) == 0;
-                u32 code;
-                if (!ll0) code = off == rep0 ? 1 : off == rep1 ? 2 : off == rep2 ? 3 : off + 3;
-                else      code = off == rep1 ? 1 : off == rep2 ? 2 : (off == rep0 - 1 && rep0 > 1) ? 3 : off + 3;
-                if (code > 3) { rep2 = rep1; rep1 = rep0; rep0 = off; }
-                else {
-                    const u32 idx = code - 1 + ll0;
-                    if (idx == 1) { const u32 tt = rep1; rep1 = rep0; rep0 = tt; }
-                    else if (idx == 2) { const u32 tt = rep2; rep2 = rep1; rep1 = rep0; rep0 = tt; }
-                    else if (idx == 3) { const u32 tt = rep0 - 1; rep2 = rep1; rep1 = rep0; rep0 = tt; }
-                }
-                if (lane == k) myCode = code;
+            const bool valid = lane < cnt;
+            const u32 off = s.offBase - 3; const bool ll0 = s.litLength == 0;
+            u32 rep0b = __shfl_up(off, 1); if (lane == 0) rep0b = R0;
+            const bool hit0 = valid && !ll0 && off == rep0b;
+            const u64 lt = lanemask_lt();
+            const u64 nh0 = ballot(valid && !hit0);
+            const u64 m1 = nh0 & lt;
+            const u32 g1 = __shfl(rep0b, m1 ? 63 - (int)__builtin_clzll(m1) : 0);
+            const u32 rep1b = m1 ? g1 : R1;
+            const bool e1 = off == rep1b, hit1 = valid && e1 && !hit0;
+            const u64 ns2 = ballot(valid && !(hit0 || hit1));
+            const u64 m2 = ns2 & lt;
+            const u32 g2 = __shfl(rep1b, m2 ? 63 - (int)__builtin_clzll(m2) : 0);
+            const u32 rep2b = m2 ? g2 : R2;
+            const bool e2 = off == rep2b, e3 = off == rep0b - 1 && rep0b > 1;
+            u32 myCode = off + 3;
+            if (!ll0) myCode = hit0 ? 1 : e1 ? 2 : e2 ? 3 : off + 3;
+            else      myCode = e1 ? 1 : e2 ? 2 : e3 ? 3 : off + 3;
+            // history after the batch = history "before sequence cnt"
+            {
+                const u64 a1 = cnt < 64 ? nh0 & ((1ull << cnt) - 1) : nh0, a2 = cnt < 64 ? ns2 & ((1ull << cnt) - 1) : ns2;
+                const u32 nR1 = a1 ? read_lane(rep0b, 63 - (u32)__builtin_clzll(a1)) : R1;
+                const u32 nR2 = a2 ? read_lane(rep1b, 63 - (u32)__builtin_clzll(a2)) : R2;
+                R0 = read_lane(off, cnt - 1); R1 = nR1; R2 = nR2;
             }
             if (i < nbSeq) sq[i].offBase = myCode;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
     __builtin_amdgcn_wave_barrier();
+    ZMI_ESTAMP(0);
     for (u32 i = lane; i < nbSeq; i += 64) {
         const Seq s = sq[i];
         atomicAdd(&W.count[0][ll_code(s.litLength)], 1u);
@@ -145,6 +170,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
+    ZMI_ESTAMP(1);
     // ---------------- serial section (lane 0): section header + the three table descriptions ----------------
     u8* op = body + m.litSectionSize;
     bool giveUp = n < 7;                 // ZSTD_buildSeqStore: blocks under MIN_CBLOCK_SIZE+header are never compressed
@@ -172,6 +198,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     bodyTablesEnd = uniform(bodyTablesEnd); typesOk = uniform(typesOk);
     tLLlog = uniform(tLLlog); tOFlog = uniform(tOFlog); tMLlog = uniform(tMLlog); tLastCount = uniform(tLastCount);
     u32 bitstreamSize = 0;
+    ZMI_ESTAMP(2);
     if (typesOk) {
         // ZSTD_encodeSequences_body (U/ZstdCompressSequences.cs:585-704), 64 sequences per step, last sequence first:
         //   lanes 0/1/2 run the LL / OF / ML state chains (they are independent of each other: a state only depends on
@@ -192,6 +219,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
             W.bCode[0][lane] = (u8)llc; W.bCode[1][lane] = (u8)ofc; W.bCode[2][lane] = (u8)mlc;
             for (u32 i = lane; i < 192; i += 64) W.tile[i] = 0;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            ZMI_ESTAMP(3);
             if (lane < 3) {
                 for (u32 k = 0; k < cnt; k++) {
                     const u32 sym = W.bCode[lane][k];
@@ -205,6 +233,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
                 }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            ZMI_ESTAMP(4);
             u64 lo = 0, hi = 0; u32 nbTot = 0;
             auto put = [&](u32 v, u32 nb) {
                 if (!nb) return;
@@ -241,6 +270,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
             outWords += fullWords;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         }
+        ZMI_ESTAMP(3);
         // FSE_flushCState x3 (ML, OF, LL) + end mark (BIT_closeCStream)
         const u32 stLL = read_lane(state, 0), stOF = read_lane(state, 1), stML = read_lane(state, 2);
         if (lane == 0) {
@@ -256,6 +286,9 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
         }
         bitstreamSize = uniform(bitstreamSize);
     }
+#ifdef ZMI_LZ_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_sencStamps[i], stampAcc[i]);
+#endif
     if (lane != 0) return;
     if (typesOk) {
         op = body + bodyTablesEnd + bitstreamSize;
@@ -290,5 +323,13 @@ void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 s
 {
     hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag, resolveReps);
 }
+
+#ifdef ZMI_LZ_STAMPS
+extern "C" void ZSTDMI_debugReadSeqEncStamps(unsigned long long* out16, int reset)
+{
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sencStamps), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_sencStamps), z, sizeof z); }
+}
+#endif
 
 } // namespace zmi
