@@ -52,49 +52,110 @@ struct SeqWaveLds {
 
 struct SeqTable { const u16* state; const SymTT* tt; u32 tableLog; };
 
-// ZSTD_selectEncodingType + ZSTD_buildCTable for one of LL/OF/ML; returns bytes written to `op`
-__device__ inline u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count, u32 maxPossible, u32 FSELog, u32 nbSeq, u32 lastCode,
-                                      const s16* defaultNorm, u32 defaultNormLog, u32 defaultMax, bool defaultAllowedByMax,
-                                      u32 strategy, u16* stateTable, SymTT* tt, u32* typeOut, u32* tableLogOut, u32* lastCountSize)
+// FSE_buildCTable_wksp (U/FseCompress.cs:20-160) by the 64 lanes of the chunk's wave; lane s stands for symbol s.  Same
+// restatement as the decoder's table build (decode.hip): low-probability symbols take the top cells in symbol order; the
+// reference's spreading visits (i*step) & mask for i = 0, 1, ... and skips cells above highThreshold, so the j-th cell it
+// keeps belongs to the symbol whose cumulative count covers j; `stateTable[cumul[s]++] = tableSize + u` in cell order is a
+// ballot rank per symbol with the counter kept in that symbol's lane; the per-symbol transforms are independent.
+__device__ __forceinline__ void fse_build_ctable_wave(u16* stateTable, SymTT* tt, const s16* norm, u32 maxSV, u32 tableLog,
+                                                      u16* cumR, u8* tableSymbol, u32 lane)
 {
-    u32 max = maxPossible, mostFrequent = 0;
-    while (!count[max]) max--;
-    for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
-    const bool isDefaultAllowed = defaultAllowedByMax ? (max <= defaultMax) : true;
-    u32 type;
-    if (mostFrequent == nbSeq) type = (isDefaultAllowed && nbSeq <= 2) ? 0 : 1;
-    else {
-        type = 2;
-        if (isDefaultAllowed) {
-            const u32 mult = 10 - strategy, dynamicFse_nbSeq_min = ((1u << defaultNormLog) * mult) >> 3;
-            if (nbSeq < dynamicFse_nbSeq_min || mostFrequent < (nbSeq >> (defaultNormLog - 1))) type = 0;
+    const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    const int nc = lane <= maxSV ? (int)norm[lane] : 0;
+    const bool low = nc == -1;
+    const u64 lowMask = ballot(low);
+    const u32 highThreshold = tableSize - 1 - popc64(lowMask);
+    if (low) tableSymbol[tableSize - 1 - popc64(lowMask & lanemask_lt())] = (u8)lane;
+    const u32 cntAll = low ? 1u : (nc > 0 ? (u32)nc : 0u), cntReg = nc > 0 ? (u32)nc : 0u;
+    const u32 inclAll = wave_scan_incl(cntAll), inclReg = wave_scan_incl(cntReg);
+    const u32 total = inclAll - cntAll;                    // cumul[s]: first state-table slot of symbol s
+    cumR[lane] = (u16)(inclReg - cntReg);
+    wave_lds_sync();
+    u32 jBase = 0;
+    for (u32 i0 = 0; i0 < tableSize; i0 += 64) {
+        const u32 i = i0 + lane, p = (i * step) & mask;
+        const bool place = i < tableSize && p <= highThreshold;
+        const u64 bal = ballot(place);
+        const u32 j = jBase + popc64(bal & lanemask_lt());
+        jBase += popc64(bal);
+        if (place) {
+            u32 lo = 0, hi = 63;
+#pragma unroll
+            for (u32 it = 0; it < 6; ++it) { const u32 mid = (lo + hi + 1) >> 1; if (cumR[mid] <= j) lo = mid; else hi = mid - 1; }
+            tableSymbol[p] = (u8)lo;
         }
     }
-    *typeOut = type;
-    if (type == 1) {            // set_rle: FSE_buildCTable_rle
-        stateTable[0] = 0; stateTable[1] = 0;
-        tt[max].deltaNbBits = 0; tt[max].deltaFindState = 0;
-        *tableLogOut = 0;
-        op[0] = (u8)lastCode;   // the reference writes codeTable[0]; every code is equal here
-        return 1;
+    wave_lds_sync();
+    u32 nxt = total;                                       // cumul[lane], advanced as cells of symbol `lane` are met
+    for (u32 u0 = 0; u0 < tableSize; u0 += 64) {
+        const u32 u = u0 + lane; const bool valid = u < tableSize;
+        const u32 sym = valid ? tableSymbol[u] : 0xFFFFu;
+        u64 rem = ballot(valid);
+        while (rem) {
+            const u32 s0 = read_lane(sym, ctz64(rem));
+            const u64 m = ballot(sym == s0);
+            const u32 baseN = read_lane(nxt, s0);
+            if (sym == s0) stateTable[baseN + popc64(m & lanemask_lt())] = (u16)(tableSize + u);
+            nxt = lane == s0 ? nxt + popc64(m) : nxt;
+            rem &= ~m;
+        }
     }
-    if (type == 0) {            // set_basic
-        for (u32 s = 0; s <= defaultMax; s++) W.norm[s] = defaultNorm[s];
-        fse_build_ctable(stateTable, tt, W.norm, defaultMax, defaultNormLog, W.cumul, W.tableSymbol);
-        *tableLogOut = defaultNormLog;
-        return 0;
+    if (lane <= maxSV) {
+        SymTT t;
+        if (nc == 0) { t.deltaNbBits = ((tableLog + 1) << 16) - (1u << tableLog); t.deltaFindState = 0; }
+        else if (nc == -1 || nc == 1) { t.deltaNbBits = (tableLog << 16) - (1u << tableLog); t.deltaFindState = (s32)(total - 1); }
+        else {
+            const u32 maxBitsOut = tableLog - highbit32((u32)nc - 1);
+            t.deltaNbBits = (maxBitsOut << 16) - ((u32)nc << maxBitsOut);
+            t.deltaFindState = (s32)(total - (u32)nc);
+        }
+        tt[lane] = t;
     }
-    {                           // set_compressed
-        u32 nbSeq_1 = nbSeq;
-        const u32 tableLog = fse_optimal_table_log(FSELog, nbSeq, max, 2);
-        if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
-        fse_normalize_count(W.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048);
-        const u32 n = fse_write_ncount(op, W.norm, max, tableLog);
-        fse_build_ctable(stateTable, tt, W.norm, max, tableLog, W.cumul, W.tableSymbol);
-        *tableLogOut = tableLog;
-        *lastCountSize = n;
-        return n;
+    wave_lds_sync();
+}
+
+// ZSTD_selectEncodingType + ZSTD_buildCTable for one of LL/OF/ML, whole wave: the decisions, FSE_normalizeCount and
+// FSE_writeNCount run on lane 0 (short), the table itself is built by all lanes.  Returns bytes written to `op` (uniform).
+__device__ __forceinline__ u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count, u32 maxPossible, u32 FSELog, u32 nbSeq, u32 lastCode,
+                                               const s16* defaultNorm, u32 defaultNormLog, u32 defaultMax, bool defaultAllowedByMax,
+                                               u32 strategy, u16* stateTable, SymTT* tt, u32* typeOut, u32* tableLogOut, u32* lastCountSize, u32 lane)
+{
+    u32 type = 0, max = 0, tableLog = 0, n = 0;
+    if (lane == 0) {
+        u32 mostFrequent = 0; max = maxPossible;
+        while (!count[max]) max--;
+        for (u32 s = 0; s <= max; s++) if (count[s] > mostFrequent) mostFrequent = count[s];
+        const bool isDefaultAllowed = defaultAllowedByMax ? (max <= defaultMax) : true;
+        if (mostFrequent == nbSeq) type = (isDefaultAllowed && nbSeq <= 2) ? 0 : 1;
+        else {
+            type = 2;
+            if (isDefaultAllowed) {
+                const u32 mult = 10 - strategy, dynamicFse_nbSeq_min = ((1u << defaultNormLog) * mult) >> 3;
+                if (nbSeq < dynamicFse_nbSeq_min || mostFrequent < (nbSeq >> (defaultNormLog - 1))) type = 0;
+            }
+        }
+        if (type == 1) {        // set_rle: FSE_buildCTable_rle
+            stateTable[0] = 0; stateTable[1] = 0;
+            tt[max].deltaNbBits = 0; tt[max].deltaFindState = 0;
+            op[0] = (u8)lastCode;   // the reference writes codeTable[0]; every code is equal here
+            n = 1;
+        } else if (type == 0) { // set_basic
+            for (u32 s = 0; s <= defaultMax; s++) W.norm[s] = defaultNorm[s];
+            max = defaultMax; tableLog = defaultNormLog;
+        } else {                // set_compressed
+            u32 nbSeq_1 = nbSeq;
+            tableLog = fse_optimal_table_log(FSELog, nbSeq, max, 2);
+            if (count[lastCode] > 1) { count[lastCode]--; nbSeq_1--; }
+            fse_normalize_count(W.norm, tableLog, count, nbSeq_1, max, nbSeq_1 >= 2048);
+            n = fse_write_ncount(op, W.norm, max, tableLog);
+        }
     }
+    type = uniform(type); max = uniform(max); tableLog = uniform(tableLog); n = uniform(n);
+    wave_lds_sync();
+    if (type != 1) fse_build_ctable_wave(stateTable, tt, W.norm, max, tableLog, W.cumul, W.tableSymbol, lane);
+    *typeOut = type; *tableLogOut = tableLog;
+    if (type == 2) *lastCountSize = n;
+    return n;
 }
 
 __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs, ChunkMeta* __restrict__ meta,
@@ -175,21 +236,25 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     u8* op = body + m.litSectionSize;
     bool giveUp = n < 7;                 // ZSTD_buildSeqStore: blocks under MIN_CBLOCK_SIZE+header are never compressed
     u32 bodyTablesEnd = 0, typesOk = 0, tLLlog = 0, tOFlog = 0, tMLlog = 0, tLastCount = 0;
-    if (lane == 0 && !giveUp) {
-        if (nbSeq < 128) *op++ = (u8)nbSeq;
-        else if (nbSeq < 0x7F00) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; op += 2; }
-        else { op[0] = 0xFF; writeLE16(op + 1, nbSeq - 0x7F00); op += 3; }
+    if (!giveUp) {
+        const u32 hdr = nbSeq < 128 ? 1u : (nbSeq < 0x7F00 ? 2u : 3u);
+        if (lane == 0) {
+            if (hdr == 1) op[0] = (u8)nbSeq;
+            else if (hdr == 2) { op[0] = (u8)((nbSeq >> 8) + 0x80); op[1] = (u8)nbSeq; }
+            else { op[0] = 0xFF; writeLE16(op + 1, nbSeq - 0x7F00); }
+        }
+        op += hdr;
     }
-    if (lane == 0 && !giveUp && nbSeq) {
+    if (!giveUp && nbSeq) {             // (uniform: every lane walks the same pointers, lane 0 stores)
         u8* const seqHead = op++;
         const Seq last = sq[nbSeq - 1];
         const u32 lastLL = ll_code(last.litLength), lastOF = highbit32(last.offBase), lastML = ml_code(last.mlBase);
         u32 LLtype, OFtype, MLtype, llLog, ofLog, mlLog, lastCountSize = 0;
-        op += build_seq_table(W, op, W.count[0], 35, 9, nbSeq, lastLL, cLL_defaultNorm, 6, 35, false, strategy, W.llState, W.llTT, &LLtype, &llLog, &lastCountSize);
-        op += build_seq_table(W, op, W.count[1], 31, 8, nbSeq, lastOF, cOF_defaultNorm, 5, 28, true,  strategy, W.ofState, W.ofTT, &OFtype, &ofLog, &lastCountSize);
-        op += build_seq_table(W, op, W.count[2], 52, 9, nbSeq, lastML, cML_defaultNorm, 6, 52, false, strategy, W.mlState, W.mlTT, &MLtype, &mlLog, &lastCountSize);
+        op += build_seq_table(W, op, W.count[0], 35, 9, nbSeq, lastLL, cLL_defaultNorm, 6, 35, false, strategy, W.llState, W.llTT, &LLtype, &llLog, &lastCountSize, lane);
+        op += build_seq_table(W, op, W.count[1], 31, 8, nbSeq, lastOF, cOF_defaultNorm, 5, 28, true,  strategy, W.ofState, W.ofTT, &OFtype, &ofLog, &lastCountSize, lane);
+        op += build_seq_table(W, op, W.count[2], 52, 9, nbSeq, lastML, cML_defaultNorm, 6, 52, false, strategy, W.mlState, W.mlTT, &MLtype, &mlLog, &lastCountSize, lane);
         // lastCountSize must be the size of the LAST compressed table description (U/ZstdCompress.cs:3196-3224)
-        *seqHead = (u8)((LLtype << 6) + (OFtype << 4) + (MLtype << 2));
+        if (lane == 0) *seqHead = (u8)((LLtype << 6) + (OFtype << 4) + (MLtype << 2));
 
         bodyTablesEnd = (u32)(op - body);
         typesOk = 1; tLLlog = llLog; tOFlog = ofLog; tMLlog = mlLog; tLastCount = lastCountSize;
