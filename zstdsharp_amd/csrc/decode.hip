@@ -6,15 +6,15 @@
 //                    chaining frame -> frame until it leaves the segment, and a scan kernel checks that every
 //                    segment's exit is the next segment's entry (anything else — embedded frames inside raw blocks, a
 //                    corrupt header — falls back to the exact serial walk, which also produces the reference's error).
-//   literals kernel: one wave per frame (frames are independent: ZSTD_decompressBegin resets repcodes/tables per frame,
+//   literals kernels: frames are independent (ZSTD_decompressBegin resets repcodes/tables per frame,
 //                    U/ZstdDecompress.cs:1933-1954; blocks inside a frame are not).  Per compressed block: Huffman
 //                    weights + X1 table in LDS (HUF_readStats U/EntropyCommon.cs:292-402, HUF_readDTableX1
-//                    U/HufDecompress.cs:80-251), the four literal streams on four lanes (U/HufDecompress.cs:342-537)
-//                    with a software-pipelined 64-bit bit window, literals written to an HBM scratch.
-//                    5 KiB of LDS per wave keeps 30 waves per CU resident, which is what hides the serial
-//                    table-lookup chain of each stream.
-//   sequences kernel: one wave per frame: FSE tables in LDS (U/ZstdDecompressBlock.cs:1571-1943), the serial sequence
-//                    state chain on lane 0 (:2360-2484), 64-lane cooperative literal / match copies (:2187-2262).
+//                    U/HufDecompress.cs:80-251), then the literal streams (U/HufDecompress.cs:342-537), written to an HBM
+//                    scratch.  Two forms: serial (8 frames per wave, a stream per lane, software-pipelined 64-bit
+//                    window) for thousands of frames, and self-synchronising (a workgroup per frame, 64 lanes per
+//                    stream) for few; see launch_decode_literals.
+//   sequences kernel: one wave per frame: FSE tables built by the wave (U/ZstdDecompressBlock.cs:1571-1943), the sequence
+//                    state chain on the scalar unit (:2360-2484), 64-lane literal / match execution (:2187-2262).
 // Results are bit-exact with the reference decoder by construction of the format; error codes follow
 // U/ZSTD_ErrorCode.cs (first failing frame wins).
 #include "zmi_device.h"

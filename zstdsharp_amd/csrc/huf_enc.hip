@@ -1,19 +1,24 @@
 // huf_enc.hip — literals section of a block on gfx950.
 //
-//   huf_build_kernel  : one 256-thread workgroup per chunk.  Four waves build the four per-stream byte
-//                       histograms in LDS (HIST_count, U/Hist.cs:67-166); lane 0 then runs the reference's
-//                       code-length construction exactly — HUF_sort / HUF_buildTree / HUF_setMaxHeight /
-//                       HUF_buildCTableFromTree (U/HufCompress.cs:377-823) — and the tree description
-//                       (HUF_writeCTable_wksp + HUF_compressWeights, U/HufCompress.cs:40-235), and takes every
-//                       raw / RLE / compressed decision of ZSTD_compressLiterals (U/ZstdCompressLiterals.cs:86-185)
-//                       and HUF_compress_internal (U/HufCompress.cs:1360-1543).  Because stream sizes follow from
-//                       histogram x code length, the whole literals section is sized before a byte is encoded.
+//   huf_hist_kernel   : one 256-thread workgroup per chunk.  Four waves build the four per-stream byte histograms in
+//                       LDS (HIST_count, U/Hist.cs:67-166; 16-byte loads, parity-split copies, the hottest byte
+//                       counted by ballot), take the compressible / RLE / raw verdict of HUF_compress_internal
+//                       (U/HufCompress.cs:1360-1543) and run HUF_sort (:520-680: parallel bucket placement, the log2
+//                       buckets quick-sorted on separate lanes exactly as the reference does).  Sorted leaves and
+//                       histograms go to the next kernel through the chunk's output slot.
+//   huf_tree_kernel   : one wave per chunk (5 KiB of LDS, ~28 chunks per CU).  The serial constructions, exactly as
+//                       the reference: HUF_buildTree / HUF_setMaxHeight / HUF_buildCTableFromTree (:377-823), the tree
+//                       description (HUF_writeCTable_wksp + HUF_compressWeights, :40-235) and every raw / RLE /
+//                       compressed decision of ZSTD_compressLiterals (U/ZstdCompressLiterals.cs:86-185).  Because
+//                       stream sizes follow from histogram x code length, the whole literals section is sized before
+//                       a byte is encoded.
 //   huf_encode_kernel : one 256-thread workgroup per chunk, wave w encodes stream w
 //                       (HUF_compress4X_usingCTable_internal, U/HufCompress.cs:1221-1321): symbols are taken last
 //                       to first, 8 per lane, their codes concatenated in registers, bit offsets come from a wave
 //                       prefix scan, and the lanes OR their bits into an LDS tile that is flushed with coalesced
 //                       dword stores.
-// Given the same literals and sequence count, the bytes produced equal the oracle's (tests/test_parity_entropy).
+// Given the same literals and sequence count, the bytes produced equal the oracle's
+// (tests/test_gpu_parity.py::test_entropy_stage_is_byte_identical_to_oracle).
 #include "zmi_device.h"
 #include "zmi_fse.h"
 

@@ -1,27 +1,31 @@
-// lz_fast.hip — level-1 ("fast" strategy) LZ match finder + parse for gfx950: one 1024-thread workgroup per 64 KiB chunk.
+// lz_fast.hip — the LZ match finders + parse for gfx950: one 1024-thread workgroup per 64 KiB chunk, chunk resident in LDS.
 //
-// Takes the place of ZSTD_compressBlock_fast_noDict_generic (U/ZstdFast.cs:96-288) + ZSTD_storeSeq
-// (U/ZstdCompressInternal.cs:204-246) for one block.  It is NOT that function's parse: the reference walks the
-// block serially, inserting only the positions it visits.  Here, per 4096-byte tile:
+// Takes the place of ZSTD_compressBlock_fast_noDict_generic (U/ZstdFast.cs:96-288), of doubleFast
+// (U/ZstdDoubleFast.cs:51-247) and of the greedy/lazy search (U/ZstdLazy.cs:1743-2032) + ZSTD_storeSeq
+// (U/ZstdCompressInternal.cs:204-246) for one block.  It is NOT those functions' parse: the reference walks the block
+// serially, inserting only the positions it visits.  Here, per 4096-position tile:
 //
-//   probe    every position is hashed (hash6, U/ZstdCompressInternal.cs:380-392) and probed by its own lane against
-//            two LDS tables — the latest occurrence in EARLIER tiles (atomicMax) and the first occurrence in THIS
-//            tile (atomicMin with a tile stamp, so it needs no clearing) — plus a register-only test for periods
-//            1..4 (runs), then verified and extended up to 32 bytes (the reference's 4-byte check, ZstdFast.cs:179-191);
+//   probe    every position is hashed by its own lane (24-bit multiplies over the first 6 bytes; the dual finder adds an
+//            8-byte and a 5-byte hash) and looks up two LDS tables — the latest occurrence in EARLIER tiles and the first
+//            occurrence in THIS tile (atomicMin with a tile stamp, so it needs no clearing); entries carry a 16-bit tag;
+//   verify   candidates whose tag matches are compared and extended up to 32 bytes (the reference's 4-byte check,
+//            ZstdFast.cs:179-191); periods 1..4 (runs) are tested in registers; the lazy finder lets a match yield to the
+//            one starting a byte later (gain rule of U/ZstdLazy.cs:1836-1870);
 //   select   the greedy left-to-right parse "next = first match at or after the end of the current one" is the orbit
-//            of a jump function over the tile; it is computed by pointer doubling with all 1024 lanes (log2 rounds,
-//            early exit through __syncthreads_or) instead of a serial walk;
+//            of a jump function over the tile: tiles with <= 64 matches are walked by wave 0, dense tiles by pointer
+//            doubling with all 1024 lanes (J -> J^4 per round, double-buffered, one barrier per round);
 //   finish   matches that hit the 32-byte cap are completed by wave 0 with 64 lanes x 8 bytes per step, in order,
 //            dropping the selections they swallow;
 //   emit     every selected match computes its own sequence in parallel (rank by popcount prefix, literal length from
 //            the previous selected match's end, backward extension as ZstdFast.cs:242-247);
-//   literals bytes not covered by a selected match are compacted 16 per lane.
+//   literals bytes not covered by a selected match are compacted 4 per lane; every wave scans the 64 coverage words
+//            itself, so the compaction needs no barrier.
 //
-// Offsets are stored raw (distance + 3); the repcode assignment, which is a serial state machine over the sequences
-// (U/ZstdDecompressBlock.cs:2387-2443), runs in seq_encode's per-chunk serial section.  All table updates are
-// commutative atomics and every parallel step is order-independent, so the output is deterministic.
+// Offsets are stored raw (distance + 3); the repcode assignment (U/ZstdDecompressBlock.cs:2387-2443 run forward) is done
+// by seq_encode.  All table updates are commutative atomics or single-writer stores and every parallel step is
+// order-independent, so the output is deterministic.
 //
-// LDS (one workgroup per CU, ~152 KiB): chunk 64 KiB (+pad) | 2 hash tables u32[8192] | tile arrays.
+// LDS (one workgroup per CU, 158 KiB): chunk 64 KiB (+pad) | 64 KiB of hash tables | tile arrays.
 // HBM traffic per chunk: read n, write literals (<= n) + 8 B per sequence.
 #include "zmi_device.h"
 
@@ -65,7 +69,6 @@ struct LzLds {
     u32 wordRank[kGroups + 1];           // selected matches before each group
     u16 jumpB[kTilePos];                 // second buffer of the doubling rounds; once they end it is reused as
                                          // endOf[r+1] = absolute end of the r-th selected match of the tile (u32[kTilePos/4+2]), endOf[0] = anchor
-    u32 waveCnt[2][16];
     u64 nzWords;                         // bit g = matchMask[g] != 0 (accumulated with atomicOr during the probe, reset per tile)
     u32 matchCount;                      // matches in the current tile (decides sparse / dense selection)
     u16 sparseList[64];                  // sparse path: the tile's matches in position order
@@ -479,7 +482,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 const bool have = lane < matchCount;
                 const u32 q = have ? L.sparseList[lane] : 0;
                 const u32 len = have ? L.tileLen[q] : 0, off = have ? L.tileOff[q] : 0;
-                u32 myEnd = 0; u64 selBits = 0; u32 cur = c0, lastEnd = cursor;
+                u32 myEnd = 0; u64 selBits = 0; u32 cur = c0;
                 for (u32 i = 0; i < matchCount; ++i) {
                     const u32 qi = read_lane(q, i);
                     if (qi < cur) continue;
@@ -488,7 +491,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (li == kLenCap) e = finish_capped(tileStart + qi, read_lane(off, i));
                     if (lane == i) myEnd = e;
                     selBits |= 1ull << i;
-                    cur = e - tileStart; lastEnd = e;
+                    cur = e - tileStart;
                 }
                 const bool sel = (selBits >> lane) & 1ull;
                 const u32 rank = popc64(selBits & lanemask_lt());

@@ -1,15 +1,16 @@
 // seq_enc.hip — sequences section + block/frame finalisation on gfx950.
 //
-// One wave per chunk, four chunks per 256-thread workgroup.  The 64 lanes build the LL/OF/ML code histograms in
-// LDS (ZSTD_seqToCodes U/ZstdCompress.cs:3069-3098 + HIST_countFast); lane 0 then runs the block's serial
-// section exactly as the reference does — ZSTD_selectEncodingType's strategy<lazy heuristic
-// (U/ZstdCompressSequences.cs:400-469), ZSTD_buildCTable (:471-582), and the three interleaved tANS state chains
-// of ZSTD_encodeSequences_body (:585-704) — writing straight into the chunk's output slot behind the literals
-// section that huf_build already sized.  The same lane then applies ZSTD_entropyCompressSeqStore's
-// "compressed enough?" rule (U/ZstdCompress.cs:3357-3392) and writes the block header (U/ZstdCompress.cs:4792)
-// and the single-segment frame header (U/ZstdCompress.cs:4817-4929).
+// One wave per chunk, four chunks per 256-thread workgroup.  The 64 lanes turn raw offsets into repcodes (the
+// decoder's history rule, U/ZstdDecompressBlock.cs:2387-2443, written as a lane-parallel recurrence) and build the
+// LL/OF/ML code histograms in LDS (ZSTD_seqToCodes U/ZstdCompress.cs:3069-3098 + HIST_countFast); lane 0 takes
+// ZSTD_selectEncodingType's strategy<lazy decisions (U/ZstdCompressSequences.cs:400-469) and runs FSE_normalizeCount /
+// FSE_writeNCount; the whole wave builds each FSE_buildCTable (:471-582); the three interleaved tANS state chains of
+// ZSTD_encodeSequences_body (:585-704) run on three lanes while 64 lanes pack the bit fields — straight into the
+// chunk's output slot behind the literals section that huf_tree already sized.  Lane 0 then applies
+// ZSTD_entropyCompressSeqStore's "compressed enough?" rule (U/ZstdCompress.cs:3357-3392) and writes the block header
+// (U/ZstdCompress.cs:4792) and the single-segment frame header (U/ZstdCompress.cs:4817-4929).
 // The state chains are serial per block by construction (U/Fse.cs:41-49); the GPU gets its parallelism from the
-// 16 384 independent chunks per GiB, which is why this kernel keeps LDS small and occupancy at 32 waves/CU.
+// 16 384 independent chunks per GiB, which is why this kernel keeps LDS small.
 #include "zmi_device.h"
 #include "zmi_fse.h"
 
