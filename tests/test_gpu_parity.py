@@ -429,3 +429,17 @@ def test_corrupted_frames_fail_cleanly(gpu_lib, oracle, forced_decoder):
                 assert out == want, "the decoders disagree on a frame the oracle accepts"
                 agree += 1
     assert errors > 100 and agree >= 0
+
+
+def test_decode_prebuilt_level5_frames_at_size(gpu_lib, oracle):
+    """BASELINE configs[4] at reduced size: decompress-only of pre-built level-5 frames (built by the oracle = the
+    reference's level-5 algorithm), bit-exact check.  Both framings: independent 64 KiB frames, and one long multi-block
+    frame with history across blocks (decoded by a single wave: correctness, not speed)."""
+    data = datagen.gen("mixed", 24 << 20, 55)
+    with z.Decompressor() as d:
+        chunked = oracle.compress(data, 5, 1, 65536)
+        assert hashlib.sha256(d.Unwrap(chunked)).hexdigest() == hashlib.sha256(data).hexdigest()
+        part = data[:6 << 20]
+        whole = oracle.compress(part, 5, 1, 0)
+        assert z.Decompressor.GetDecompressedSize(whole) == len(part)
+        assert d.Unwrap(whole) == part
