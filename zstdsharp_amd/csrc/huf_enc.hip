@@ -635,22 +635,23 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
         for (u32 i = lane; i < kTileWords; i += 64) tile[i] = 0;
         // lane handles reversed indices k0 + lane*8 .. +7  ->  source bytes len-1-k, descending
         const u32 kb = k0 + lane * kSymPerLane;
-        u64 lo = 0, hi = 0; u32 nb = 0;
         // the lane's 8 symbols sit in 8 consecutive bytes (descending): one unaligned 8-byte load when all are in range
         const bool full8 = kb + kSymPerLane <= len;
         const u64 pack = full8 ? *reinterpret_cast<const u64u*>(sym + (len - kSymPerLane - kb)) : 0;
+        // codes are at most 11 bits: symbols 0..4 fit one 64-bit accumulator (<= 55 bits), symbols 5..7 another (<= 33),
+        // so the per-symbol step is a plain shift-or; the two halves are joined once
+        u64 accA = 0, accB = 0; u32 nA = 0, nB = 0;
 #pragma unroll
         for (u32 j = 0; j < kSymPerLane; j++) {
             const u32 k = kb + j;
-            if (k < len) {
-                const u32 s8 = full8 ? (u32)(pack >> (8 * (kSymPerLane - 1 - j))) & 0xFFu : (u32)sym[len - 1 - k];
-                const u32 e = L.ct[s8];
-                const u64 code = e & 0xFFFF; const u32 b = e >> 16;
-                if (nb < 64) { lo |= code << nb; if (nb + b > 64) hi |= code >> (64 - nb); }
-                else hi |= code << (nb - 64);
-                nb += b;
-            }
+            const u32 s8 = full8 ? (u32)(pack >> (8 * (kSymPerLane - 1 - j))) & 0xFFu : (k < len ? (u32)sym[len - 1 - k] : 0u);
+            const u32 e = k < len ? L.ct[s8] : 0u;
+            const u64 code = e & 0xFFFF; const u32 b = e >> 16;
+            if (j < 5) { accA |= code << nA; nA += b; } else { accB |= code << nB; nB += b; }
         }
+        const u32 nb = nA + nB;
+        const u64 lo = accA | (nA < 64 ? accB << nA : 0ull);
+        const u64 hi = nA ? accB >> (64 - nA) : 0ull;
         const u32 incl = wave_scan_incl(nb);
         const u32 tileBits = read_lane(incl, 63);
         const u32 bitOff = carryBits + incl - nb;
