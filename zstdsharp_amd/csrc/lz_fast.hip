@@ -259,6 +259,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(1);
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
         ZMI_STAMP(2);
+        u64 mmJ[kPPT], cmJ[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = j * kTile + tid, p = tileStart + q;
@@ -351,11 +352,18 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 }
             }
             if (len) { L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off; }      // only read where matchMask has the bit
-            const u64 mm = ballot(len != 0), cm = ballot(len == kLenCap);
-            if (lane == 0) {
-                const u32 g = j * 16 + wave;
-                L.matchMask[g] = mm; L.capMask[g] = cm; L.selMask[g] = 0; L.covMask[g] = 0;
-                if (mm) { atomicOr((unsigned long long*)&L.nzWords, 1ull << g); atomicAdd(&L.matchCount, popc64(mm)); }
+            mmJ[j] = ballot(len != 0); cmJ[j] = ballot(len == kLenCap);
+        }
+        {   // the wave's four groups of masks are written together by lanes 0..3 (one predicated block instead of four)
+            u64 mmL = mmJ[0], cmL = cmJ[0];
+#pragma unroll
+            for (u32 j = 1; j < kPPT; ++j) { mmL = lane == j ? mmJ[j] : mmL; cmL = lane == j ? cmJ[j] : cmL; }
+            const u32 nMatch = popc64(mmJ[0]) + popc64(mmJ[1]) + popc64(mmJ[2]) + popc64(mmJ[3]);
+            if (lane < kPPT) {
+                const u32 g = lane * 16 + wave;
+                L.matchMask[g] = mmL; L.capMask[g] = cmL; L.selMask[g] = 0; L.covMask[g] = 0;
+                if (mmL) atomicOr((unsigned long long*)&L.nzWords, 1ull << g);
+                if (lane == 0 && nMatch) atomicAdd(&L.matchCount, nMatch);
             }
         }
         ZMI_STAMP(3);
