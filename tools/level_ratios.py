@@ -5,6 +5,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import datagen, oracle_lib as o
 import zstdsharp_amd as z
+if os.environ.get('ZMI_LIB'):
+    z._ffi.LIB_PATH = os.path.join(ROOT, 'zstdsharp_amd', os.environ['ZMI_LIB'])
 
 import glob
 def corpus(kind):
