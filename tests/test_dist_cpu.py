@@ -25,7 +25,18 @@ def _worker(rank, world, port, total, q):
         buf = torch.cat([buf, torch.zeros(pad - buf.numel(), dtype=torch.uint8)])
     out = all_gather_v(buf, mine.numel(), sizes)
     expect = torch.cat([data[slice(*shard_range(total, r, world))][::3] for r in range(world)])
-    q.put((rank, lo, hi, sizes, bool(torch.equal(out, expect))))
+    ok = bool(torch.equal(out, expect))
+    # the bench's form: sizes on their own process group, caller-owned (oversized) staging and output buffers, padded slots
+    pg = dist.new_group(backend="gloo")
+    sizes2 = all_gather_sizes(mine.numel(), "cpu", group=pg)
+    pad2 = (max(sizes2) + 63) // 64 * 64
+    if buf.numel() < pad2:
+        buf = torch.cat([buf, torch.zeros(pad2 - buf.numel(), dtype=torch.uint8)])
+    stage = torch.empty(world * pad2 + 1000, dtype=torch.uint8); outb = torch.empty(sum(sizes2) + 1000, dtype=torch.uint8)
+    for _ in range(2):                       # buffers are reused step after step
+        out2 = all_gather_v(buf, mine.numel(), sizes2, out=outb, pad_to=pad2, staging=stage)
+        ok = ok and sizes2 == sizes and bool(torch.equal(out2, expect))
+    q.put((rank, lo, hi, sizes, ok))
     dist.barrier(); dist.destroy_process_group()
 
 
