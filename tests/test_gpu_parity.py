@@ -443,3 +443,30 @@ def test_decode_prebuilt_level5_frames_at_size(gpu_lib, oracle):
         whole = oracle.compress(part, 5, 1, 0)
         assert z.Decompressor.GetDecompressedSize(whole) == len(part)
         assert d.Unwrap(whole) == part
+
+
+def test_boundary_sizes_differential(gpu_lib, oracle, forced_decoder):
+    """Sizes around tile (4096), chunk (65536) and pass boundaries, every finder, every data kind: GPU frames decode under the
+    oracle and under both GPU literal decoders; oracle frames decode on the GPU."""
+    import random
+    rng = random.Random(77)
+    d = forced_decoder
+    sizes = set()
+    for base in (4096, 8192, 61440, 65536, 131072, 196608):
+        for delta in (-9, -8, -7, -1, 0, 1, 7, 8, 9):
+            sizes.add(base + delta)
+    sizes |= {rng.randrange(1, 300000) for _ in range(25)}
+    comps = {lvl: z.Compressor(lvl) for lvl in (1, 3, 6)}
+    try:
+        for n in sorted(sizes):
+            kind = rng.choice(datagen.KINDS)
+            data = datagen.gen(kind, n, n)
+            for lvl, c in comps.items():
+                comp = c.Wrap(data)
+                assert d.Unwrap(comp) == data, (kind, n, lvl)
+                if lvl == 1 or n % 7 == 0:
+                    assert oracle.decompress(comp, n) == data, (kind, n, lvl)
+            assert d.Unwrap(oracle.compress(data, 1, n & 1, 65536)) == data, (kind, n)
+    finally:
+        for c in comps.values():
+            c.Dispose()
