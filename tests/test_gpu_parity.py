@@ -470,3 +470,20 @@ def test_boundary_sizes_differential(gpu_lib, oracle, forced_decoder):
     finally:
         for c in comps.values():
             c.Dispose()
+
+
+def test_repeat_after_incompressible_data_is_found(gpu_lib, oracle):
+    """The match finder probes sparsely where the previous tile found nothing (as ZSTD_fast's growing step does); a repeat
+    of incompressible data at an arbitrary distance must still be found (the probe lattice is jittered for that)."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    for shift in (0, 1, 2, 3, 5, 13):
+        block = rng.integers(0, 256, 30000, dtype=np.uint8).tobytes()
+        chunk = block + bytes(rng.integers(0, 256, 100 + shift, dtype=np.uint8)) + block
+        data = chunk * 3 + block[:5000]
+        for level in (1, 5):
+            with z.Compressor(level) as c, z.Decompressor() as d:
+                comp = c.Wrap(data)
+                assert d.Unwrap(comp) == data
+                ref = len(oracle.compress(data, 1, 0, 65536))
+                assert len(comp) <= ref * 1.10 + 512, (shift, level, len(comp), ref, len(data))

@@ -233,16 +233,30 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 
     // Matches may start where 8 bytes are still readable (the reference stops at iend-8, ZstdFast.cs:110).
     const u32 nTiles = (n + kTilePos - 1) / kTilePos;
+    // Where the previous tile found next to nothing, this tile probes every 2nd or 4th position only — the reference's own
+    // acceleration (ZSTD_fast's step = 1 + ((ip - anchor) >> kSearchStrength), U/ZstdFast.cs:130-136).  A match that starts
+    // between probed positions is still picked up one or two bytes later and grown backward at emission.
+    u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     for (u32 t = 0; t < nTiles; ++t) {
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
+        const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
+        const u32 nPass = kPPT >> strideLog;
+        // probed position of lattice cell c = j * kTile + tid: c * stride + a pseudo-random residue, so that a repeat of
+        // earlier data lines up with inserted positions one time in `stride` whatever its distance (a fixed lattice would
+        // never see a repeat whose distance is not a multiple of the stride)
+        auto probed = [&](u32 j) -> u32 {
+            const u32 cI = j * kTile + tid;
+            return (cI << strideLog) + ((((tileStart >> kTileLog) * kTilePos + cI) * 2654435761u >> 27) & ((1u << strideLog) - 1));
+        };
         // ---------------- probe ----------------
         // fast: h = hash product, cand = table entry.  dual: h = long product, h2 = short product, cand = tableL | tableS << 16
         u64 w[kPPT]; u32 h[kPPT], h2[kPPT], cand[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = tileStart + q;
-            valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
+            const u32 q = probed(j), p = tileStart + q;
+            valid[j] = j < nPass && p + 8 <= n; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
+            if (j >= nPass) continue;            // uniform
             if (valid[j]) {
                 w[j] = lds_load8(L.in, p);
                 if (MODE == 0) {
@@ -260,9 +274,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         __syncthreads();                       // every probe of this tile precedes every insert of this tile
         ZMI_STAMP(2);
         u64 mmJ[kPPT], cmJ[kPPT];
+        if (strideLog != 0 && lane < 4) {        // strided tile: a wave's probes fall into its own four groups; matching lanes set bits below
+            const u32 g = strideLog == 2 ? wave * 4 + lane : (lane >> 1) * 32 + wave * 2 + (lane & 1);
+            L.matchMask[g] = 0; L.capMask[g] = 0; L.selMask[g] = 0; L.covMask[g] = 0;
+        }
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = tileStart + q;
+            mmJ[j] = 0; cmJ[j] = 0;
+            if (j >= nPass) continue;            // uniform
+            const u32 q = probed(j), p = tileStart + q;
             u32 len = 0, off = 0;
             if (valid[j]) {
                 if (MODE == 0) atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | htag(h[j]));
@@ -340,7 +360,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 // a 4-byte match far away costs more than its literals (offset bits + three codes against ~5 bits a byte)
                 if (len == 4 && off >= 256) len = 0;
             }
-            if (MODE == 2) {
+            if (MODE == 2 && strideLog == 0) {
                 // lazy deferral (U/ZstdLazy.cs:1836-1870): a match yields to the one starting one byte later when that one
                 // gains more (4 bits per byte saved, minus log2 of the offset, plus 4 for the literal it costs).  The next
                 // position lives in the next lane; the last lane of a wave keeps its match.
@@ -353,11 +373,19 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
             if (len) { L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off; }      // only read where matchMask has the bit
             mmJ[j] = ballot(len != 0); cmJ[j] = ballot(len == kLenCap);
+            if (strideLog != 0) {
+                if (len) {
+                    atomicOr((unsigned long long*)&L.matchMask[q >> 6], 1ull << (q & 63));
+                    if (len == kLenCap) atomicOr((unsigned long long*)&L.capMask[q >> 6], 1ull << (q & 63));
+                    atomicOr((unsigned long long*)&L.nzWords, 1ull << (q >> 6));
+                }
+                if (lane == 0 && mmJ[j]) atomicAdd(&L.matchCount, popc64(mmJ[j]));
+            }
         }
-        {   // the wave's four groups of masks are written together by lanes 0..3 (one predicated block instead of four)
+        if (strideLog == 0) {   // the wave's four groups of masks are written together by lanes 0..3 (one predicated block instead of four)
             u64 mmL = mmJ[0], cmL = cmJ[0];
 #pragma unroll
-            for (u32 j = 1; j < kPPT; ++j) { mmL = lane == j ? mmJ[j] : mmL; cmL = lane == j ? cmJ[j] : cmL; }
+            for (u32 k = 1; k < kPPT; ++k) { mmL = lane == k ? mmJ[k] : mmL; cmL = lane == k ? cmJ[k] : cmL; }
             const u32 nMatch = popc64(mmJ[0]) + popc64(mmJ[1]) + popc64(mmJ[2]) + popc64(mmJ[3]);
             if (lane < kPPT) {
                 const u32 g = lane * 16 + wave;
@@ -371,6 +399,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
         const u32 matchCount = L.matchCount;
+        prevDensity = matchCount << strideLog;
         const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
         const bool dense = any && matchCount > 64;
         if (dense) {
