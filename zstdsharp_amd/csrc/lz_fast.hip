@@ -69,8 +69,8 @@ struct LzLds {
     u32 wordRank[kGroups + 1];           // selected matches before each group
     u16 jumpB[kTilePos];                 // second buffer of the doubling rounds; once they end it is reused as
                                          // endOf[r+1] = absolute end of the r-th selected match of the tile (u32[kTilePos/4+2]), endOf[0] = anchor
-    u64 nzWords;                         // bit g = matchMask[g] != 0 (accumulated with atomicOr during the probe, reset per tile)
-    u32 matchCount;                      // matches in the current tile (decides sparse / dense selection)
+    u64 nzWords[2];                      // bit g = matchMask[g] != 0 (accumulated with atomicOr during verify); slot = tile parity
+    u32 matchCount[2];                   // matches in the current tile (decides sparse / dense selection); slot = tile parity
     u16 sparseList[64];                  // sparse path: the tile's matches in position order
 };
 
@@ -135,13 +135,13 @@ __device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w,
 }
 
 // first match position >= c inside the tile (tile-relative), or kExit
-__device__ __forceinline__ u32 next_match(const LzLds& L, u32 c)
+__device__ __forceinline__ u32 next_match(const LzLds& L, u32 c, u32 par)
 {
     if (c >= kTilePos) return kExit;
     const u32 wi = c >> 6;
     const u64 w = L.matchMask[wi] >> (c & 63);
     if (w) return c + ctz64(w);
-    const u64 rest = wi + 1 < kGroups ? (L.nzWords >> (wi + 1)) : 0;
+    const u64 rest = wi + 1 < kGroups ? (L.nzWords[par] >> (wi + 1)) : 0;
     if (!rest) return kExit;
     const u32 wj = wi + 1 + ctz64(rest);
     return wj * 64 + ctz64(L.matchMask[wj]);
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         if (MODE == 0) { table[i] = 0; first[i] = 0xFFFFFFFFu; }
         else           { L.tabMem[i] = 0xFFFFFFFFu; L.tabMem[(1u << kHashLog) + i] = 0; }
     }
-    if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }
+    if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; }
     __syncthreads();
     ZMI_STAMP(0);
 
@@ -241,7 +241,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
-        const u32 nPass = kPPT >> strideLog;
+        const u32 nPass = kPPT >> strideLog, par = t & 1;
         // probed position of lattice cell c = j * kTile + tid: c * stride + a pseudo-random residue, so that a repeat of
         // earlier data lines up with inserted positions one time in `stride` whatever its distance (a fixed lattice would
         // never see a repeat whose distance is not a multiple of the stride)
@@ -377,9 +377,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 if (len) {
                     atomicOr((unsigned long long*)&L.matchMask[q >> 6], 1ull << (q & 63));
                     if (len == kLenCap) atomicOr((unsigned long long*)&L.capMask[q >> 6], 1ull << (q & 63));
-                    atomicOr((unsigned long long*)&L.nzWords, 1ull << (q >> 6));
+                    atomicOr((unsigned long long*)&L.nzWords[par], 1ull << (q >> 6));
                 }
-                if (lane == 0 && mmJ[j]) atomicAdd(&L.matchCount, popc64(mmJ[j]));
+                if (lane == 0 && mmJ[j]) atomicAdd(&L.matchCount[par], popc64(mmJ[j]));
             }
         }
         if (strideLog == 0) {   // the wave's four groups of masks are written together by lanes 0..3 (one predicated block instead of four)
@@ -390,15 +390,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             if (lane < kPPT) {
                 const u32 g = lane * 16 + wave;
                 L.matchMask[g] = mmL; L.capMask[g] = cmL; L.selMask[g] = 0; L.covMask[g] = 0;
-                if (mmL) atomicOr((unsigned long long*)&L.nzWords, 1ull << g);
-                if (lane == 0 && nMatch) atomicAdd(&L.matchCount, nMatch);
+                if (mmL) atomicOr((unsigned long long*)&L.nzWords[par], 1ull << g);
+                if (lane == 0 && nMatch) atomicAdd(&L.matchCount[par], nMatch);
             }
         }
         ZMI_STAMP(3);
         __syncthreads();
         ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
-        const u32 matchCount = L.matchCount;
+        const u32 matchCount = L.matchCount[par];
         prevDensity = matchCount << strideLog;
         const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
         const bool dense = any && matchCount > 64;
@@ -410,9 +410,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             for (u32 j = 0; j < kPPT; ++j) {
                 const u32 q = j * kTile + tid;
                 has[j] = (L.matchMask[q >> 6] >> (q & 63)) & 1ull;
-                if (has[j]) cur[q] = (u16)next_match(L, q + L.tileLen[q]);
+                if (has[j]) cur[q] = (u16)next_match(L, q + L.tileLen[q], par);
             }
-            const u32 s0 = next_match(L, c0);                       // uniform: first match at or after the entry cursor
+            const u32 s0 = next_match(L, c0, par);                       // uniform: first match at or after the entry cursor
             if (tid == 0 && s0 != kExit) L.selMask[s0 >> 6] = 1ull << (s0 & 63);
             __syncthreads();
             // Each round replaces J by J^4 (double-buffered, one barrier) and lets every selected position mark J, J^2, J^3
@@ -538,13 +538,19 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                 if (sel) emit_match(tileStart, q, rank, myEnd);
             }
-        } else if (tid == 0) L.wordRank[64] = 0;
+        }
         ZMI_STAMP(5);
-        __syncthreads();
+        if (any) __syncthreads();              // (uniform) a tile without a selection has nothing to hand over
         ZMI_STAMP(6);
-        const u32 nSel = L.wordRank[64];
+        const u32 nSel = any ? L.wordRank[64] : 0u;
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
-        {
+        if (!any && c0 == 0 && tileStart + kTilePos <= n) {
+            // nothing selected, nothing carried in, full tile: every byte is a literal, copied straight through
+            const u32 q4 = tid * 4;
+            *(u32u*)(litOut + litBase + q4) = *reinterpret_cast<const u32*>(L.in + tileStart + q4);
+            litBase += kTilePos;
+            if (tid == 0) { L.nzWords[par ^ 1] = 0; L.matchCount[par ^ 1] = 0; }
+        } else {
             // Every wave scans the 64 group words itself (one LDS read per lane), so the compaction offsets need neither a
             // cross-wave table nor another barrier.  keepG(g) = bytes of group g that are literals of this tile.
             auto keepG = [&](u32 g) -> u64 {
@@ -571,7 +577,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
             }
             litBase += total; nbSeq += nSel; cursor = lastEnd;
-            if (tid == 0) { L.nzWords = 0; L.matchCount = 0; }     // next tile's probe phase sits behind its own barrier
+            if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; }     // next tile's probe phase sits behind its own barrier
         }
         ZMI_STAMP(7);
     }
