@@ -242,6 +242,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
         const u32 nPass = kPPT >> strideLog, par = t & 1;
+        // sparse tile of the fast finder: no in-tile candidates, table inserts after the verify barrier -> one barrier less
+        const bool fused = MODE == 0 && strideLog != 0;
         // probed position of lattice cell c = j * kTile + tid: c * stride + a pseudo-random residue, so that a repeat of
         // earlier data lines up with inserted positions one time in `stride` whatever its distance (a fixed lattice would
         // never see a repeat whose distance is not a multiple of the stride)
@@ -261,7 +263,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 w[j] = lds_load8(L.in, p);
                 if (MODE == 0) {
                     h[j] = hash6p(w[j]);
-                    cand[j] = table[hidx(h[j])]; atomicMin(&first[hidx(h[j])], ((stamp | q) << 16) | htag(h[j]));
+                    cand[j] = table[hidx(h[j])];
+                    if (!fused) atomicMin(&first[hidx(h[j])], ((stamp | q) << 16) | htag(h[j]));
                 } else {
                     h[j] = hash8p(w[j]); h2[j] = hash_shortp<SHORT>(w[j]);
                     const u32 hL = hidx(h[j]), hS = hidx(h2[j]);
@@ -271,7 +274,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
         }
         ZMI_STAMP(1);
-        __syncthreads();                       // every probe of this tile precedes every insert of this tile
+        if (!fused) __syncthreads();           // every probe of this tile precedes every insert of this tile
         ZMI_STAMP(2);
         u64 mmJ[kPPT], cmJ[kPPT];
         if (strideLog != 0 && lane < 4) {        // strided tile: a wave's probes fall into its own four groups; matching lanes set bits below
@@ -285,7 +288,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             const u32 q = probed(j), p = tileStart + q;
             u32 len = 0, off = 0;
             if (valid[j]) {
-                if (MODE == 0) atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | htag(h[j]));
+                if (MODE == 0 && !fused) atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | htag(h[j]));
                 // (1) periods 1..4: bytes p..p+7 repeat with period d and the d bytes before p agree — runs and tiny
                 //     patterns, which neither table can see inside one tile
                 u32 per = 0;
@@ -307,9 +310,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
                     else {
                         // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
-                        const u32 f = first[hidx(h[j])], tag = htag(h[j]);
+                        const u32 tag = htag(h[j]);
+                        const u32 f = fused ? 0xFFFFFFFFu : first[hidx(h[j])];
                         const u32 fq = (f >> 16) & (kTilePos - 1);
-                        if (fq < q && (f & 0xFFFFu) == tag) {
+                        if (!fused && fq < q && (f & 0xFFFFu) == tag) {
                             const u32 cpos = tileStart + fq;
                             len = match_len(L, p, cpos, w[j], n); off = p - cpos;
                         }
@@ -399,6 +403,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
         const u32 matchCount = L.matchCount[par];
+        if (fused) {                           // the deferred inserts of a sparse tile (every probe of the tile came before the barrier)
+#pragma unroll
+            for (u32 j = 0; j < kPPT; ++j) if (valid[j]) atomicMax(&table[hidx(h[j])], ((tileStart + probed(j) + 1) << 16) | htag(h[j]));
+        }
         prevDensity = matchCount << strideLog;
         const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
         const bool dense = any && matchCount > 64;
