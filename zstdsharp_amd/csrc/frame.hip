@@ -59,7 +59,10 @@ __global__ __launch_bounds__(256) void gather_kernel(const u8* __restrict__ src,
     u8* d = dst + off;
     const u32 tail = m.outSize - (m.fhSize + 3) - (m.blockType == 2 ? m.bodySize : m.srcSize);   // 0 or 4 (checksum)
     if (m.blockType == 2) {
-        copy_bytes(d, slot, m.fhSize + 3 + m.bodySize, tid, 256);
+        // the literals section is already in place (huf_encode writes it there); headers and the sequences section follow
+        const u32 head = m.fhSize + 3, seqAt = head + m.litSectionSize;
+        if (tid < head) d[tid] = slot[tid];
+        copy_bytes(d + seqAt, slot + seqAt, head + m.bodySize - seqAt, tid, 256);
     } else {
         if (tid < m.fhSize + 3) d[tid] = slot[tid];
         copy_bytes(d + m.fhSize + 3, src + ((u64)c << kChunkLog), m.srcSize, tid, 256);

@@ -580,8 +580,11 @@ struct HufEncLds {
     u32 tile[4][kTileWords];
 };
 
+// `dst` != nullptr: the literals section goes straight to its final place in the output (offsets[] from the scan; the
+// sequences section and the headers follow through gather_kernel); nullptr: into the chunk's slot (test hook).
 __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ lits, const ChunkMeta* __restrict__ meta,
-                                                         const HufTable* __restrict__ tables, u8* __restrict__ slots)
+                                                         const HufTable* __restrict__ tables, u8* __restrict__ slots,
+                                                         u8* __restrict__ dst, const u64* __restrict__ offsets, u64 dstCapacity)
 {
     __shared__ HufEncLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -589,6 +592,12 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     const u32 litSize = m.litSize;
     const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
     u8* __restrict__ body = slots + (u64)c * kSlotStride + m.fhSize + 3;      // block body starts after frame + block header
+    if (dst) {
+        if (m.blockType != 2) return;                                        // stored raw: gather copies the source bytes
+        const u64 off = offsets[c];
+        if (off + m.outSize > dstCapacity) return;                           // host reports dstSize_tooSmall from the scanned total
+        body = dst + off + m.fhSize + 3;
+    }
 
     if (m.litMode != kLitCompressed) {
         // ZSTD_noCompressLiterals / ZSTD_compressRleLiteralsBlock (U/ZstdCompressLiterals.cs:8-83)
@@ -689,9 +698,10 @@ void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slo
     hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots);
     hipLaunchKernelGGL(huf_tree_kernel, dim3(nChunks), dim3(64), 0, stream, meta, tables, slots);
 }
-void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream)
+void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
+                       u32 nChunks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(huf_encode_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables, slots);
+    hipLaunchKernelGGL(huf_encode_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables, slots, dst, offsets, dstCapacity);
 }
 
 } // namespace zmi

@@ -17,7 +17,8 @@ namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
-void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
+void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
+                       u32 nChunks, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream);
 void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
 void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
@@ -183,11 +184,12 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         if (first) c->timer.begin(s);
         launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, s);                      if (first) c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, s);                        if (first) c->timer.mark("huf_build", s);
-        launch_huf_encode(lits, meta, tables, slots, nChunks, s);                  if (first) c->timer.mark("huf_encode", s);
         if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, s);             if (first) c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, s);   if (first) c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       if (first) c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
+        // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
+        launch_huf_encode(lits, meta, tables, slots, d_dst + produced, offsets, room, nChunks, s);   if (first) c->timer.mark("huf_encode", s);
         launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, s);      if (first) c->timer.mark("gather", s);
         u64 passTotal = 0;
         if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
@@ -730,7 +732,7 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (litSize) (void)hipMemcpyAsync(c->lits.p, lits, litSize, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
     launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
-    launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
+    launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, s);
     launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, strategy_for_level(c->level), 0, 0, s);
     if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
