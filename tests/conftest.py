@@ -32,6 +32,11 @@ def golden():
 @pytest.fixture(scope="session")
 def gpu_lib():
     """The product library, bound through its C ABI.  Fails (not skips) if it cannot drive a GPU."""
+    # torch first: the wheel bundles its own copy of the HIP runtime, and it cannot enumerate the GPU once the system
+    # runtime behind libzstd_mi355x.so holds it; the other order works (it is also bench.py's order)
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a visible MI355X"
+    torch.zeros(1, device="cuda")
     import zstdsharp_amd
     lib = zstdsharp_amd._ffi.load()
     assert lib.ZSTDMI_deviceCount() > 0, "no gfx950 device visible: GPU tests need the HIP path, there is no fallback"

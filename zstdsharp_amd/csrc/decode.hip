@@ -1427,103 +1427,131 @@ struct SpanChain {
     }
 };
 
-// up to 4 symbols of chain A and of chain B, interleaved; returns the packed symbols (valid ones counted in kA / kB)
+constexpr u32 kChains = 4;              // independent lookup chains per lane (adjacent spans of the same stream)
+
+// up to 4 symbols of each of the lane's chains, interleaved instruction by instruction; packed symbols in w[], counts in k[]
 template <bool STAGED, bool WRITE>
-__device__ __forceinline__ void span_group2(const u16* __restrict__ table, const u32 sh, const u8* __restrict__ sb, const s32 size,
-                                            SpanChain<STAGED>& A, SpanChain<STAGED>& B, u32& wA, u32& wB, u32& kA, u32& kB)
+__device__ __forceinline__ void span_group(const u16* __restrict__ table, const u32 sh, const u8* __restrict__ sb, const s32 size,
+                                           SpanChain<STAGED> (&C)[kChains], u32 (&w)[kChains], u32 (&k)[kChains])
 {
-    const u64 cA = A.load8(sb, size), cB = B.load8(sb, size);
-    const u32 limA = (u32)(8 * (A.ptr + 8) - A.lo), limB = (u32)(8 * (B.ptr + 8) - B.lo);
-    u32 conA = A.consumed, conB = B.consumed, mA = A.more, mB = B.more;
-    wA = 0; wB = 0; kA = 0; kB = 0;
+    u64 cont[kChains]; u32 lim[kChains], con[kChains], m[kChains];
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) {
+        cont[c] = C[c].load8(sb, size);
+        lim[c] = (u32)(8 * (C[c].ptr + 8) - C[c].lo); con[c] = C[c].consumed; m[c] = C[c].more;
+        w[c] = 0; k[c] = 0;
+    }
 #pragma unroll
     for (u32 j = 0; j < 4; ++j) {
-        const u32 eA = table[(u32)((cA << (conA & 63)) >> 32) >> sh];
-        const u32 eB = table[(u32)((cB << (conB & 63)) >> 32) >> sh];
-        conA += mA ? (eA >> 8) : 0u; conB += mB ? (eB >> 8) : 0u;
-        kA += mA; kB += mB;
-        if (WRITE) { wA |= (mA ? (eA & 0xFFu) : 0u) << (8 * j); wB |= (mB ? (eB & 0xFFu) : 0u) << (8 * j); }
-        mA = mA & (conA < limA); mB = mB & (conB < limB);
+        u32 e[kChains];
+#pragma unroll
+        for (u32 c = 0; c < kChains; ++c) e[c] = table[(u32)((cont[c] << (con[c] & 63)) >> 32) >> sh];
+#pragma unroll
+        for (u32 c = 0; c < kChains; ++c) {
+            con[c] += m[c] ? (e[c] >> 8) : 0u;
+            k[c] += m[c];
+            if (WRITE) w[c] |= (m[c] ? (e[c] & 0xFFu) : 0u) << (8 * j);
+            m[c] = m[c] & (con[c] < lim[c]);
+        }
     }
-    A.ptr -= (s32)(conA >> 3); A.consumed = conA & 7; A.more = mA; A.cnt += kA;
-    B.ptr -= (s32)(conB >> 3); B.consumed = conB & 7; B.more = mB; B.cnt += kB;
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) { C[c].ptr -= (s32)(con[c] >> 3); C[c].consumed = con[c] & 7; C[c].more = m[c]; C[c].cnt += k[c]; }
 }
 
-// run both chains of a lane to the end of their spans; WRITE: symbols to outA / outB, 16 per store
+// run all chains of a lane to the end of their spans; WRITE: symbols to out[c], 16 per store
 template <bool STAGED, bool WRITE>
-__device__ __forceinline__ void span_run2(const u16* __restrict__ table, const u32 tableLog, const u8* __restrict__ sb, const s32 size,
-                                          SpanChain<STAGED>& A, SpanChain<STAGED>& B, u8* __restrict__ outA, u8* __restrict__ outB)
+__device__ __forceinline__ void span_run(const u16* __restrict__ table, const u32 tableLog, const u8* __restrict__ sb, const s32 size,
+                                         SpanChain<STAGED> (&C)[kChains], u8* (&out)[kChains])
 {
     const u32 sh = 32 - tableLog;
-    while (A.more | B.more) {
-        u32 wa[4], wb[4], ka[4], kb[4];
+    for (;;) {
+        u32 any = 0;
 #pragma unroll
-        for (u32 g = 0; g < 4; ++g) span_group2<STAGED, WRITE>(table, sh, sb, size, A, B, wa[g], wb[g], ka[g], kb[g]);
+        for (u32 c = 0; c < kChains; ++c) any |= C[c].more;
+        if (!any) break;
+        u32 w4[4][kChains], k4[4][kChains];
+#pragma unroll
+        for (u32 g = 0; g < 4; ++g) span_group<STAGED, WRITE>(table, sh, sb, size, C, w4[g], k4[g]);
         if (WRITE) {
-            const u32 nA = ka[0] + ka[1] + ka[2] + ka[3], nB = kb[0] + kb[1] + kb[2] + kb[3];
-            if (nA == 16) { u32u* o = (u32u*)outA; o[0] = wa[0]; o[1] = wa[1]; o[2] = wa[2]; o[3] = wa[3]; }
-            else { u32 t = 0; for (u32 g = 0; g < 4; ++g) for (u32 j = 0; j < 4; ++j) if (j < ka[g]) outA[t++] = (u8)(wa[g] >> (8 * j)); }
-            if (nB == 16) { u32u* o = (u32u*)outB; o[0] = wb[0]; o[1] = wb[1]; o[2] = wb[2]; o[3] = wb[3]; }
-            else { u32 t = 0; for (u32 g = 0; g < 4; ++g) for (u32 j = 0; j < 4; ++j) if (j < kb[g]) outB[t++] = (u8)(wb[g] >> (8 * j)); }
-            outA += nA; outB += nB;
+#pragma unroll
+            for (u32 c = 0; c < kChains; ++c) {
+                const u32 nC = k4[0][c] + k4[1][c] + k4[2][c] + k4[3][c];
+                if (nC == 16) { u32u* o = (u32u*)out[c]; o[0] = w4[0][c]; o[1] = w4[1][c]; o[2] = w4[2][c]; o[3] = w4[3][c]; }
+                else { u32 t = 0; for (u32 g = 0; g < 4; ++g) for (u32 j = 0; j < 4; ++j) if (j < k4[g][c]) out[c][t++] = (u8)(w4[g][c] >> (8 * j)); }
+                out[c] += nC;
+            }
         }
     }
 }
 
 // one stream on one wave; true iff it decodes to exactly n symbols and is consumed to its first bit.  The stream's bits
-// are cut into 128 spans, two ADJACENT ones per lane (two independent lookup chains per lane hide each other's LDS
-// latency).  Every span first decodes a short run-in above its upper boundary to fall into step, so its first guess of its
-// own start is almost always the true one; starts are then corrected from the span above until none changes.
+// are cut into 64 x kChains spans, kChains ADJACENT ones per lane (independent lookup chains of a lane hide each other's
+// LDS latency).  Every span first decodes a short run-in above its upper boundary to fall into step, so its first guess of
+// its own start is almost always the true one; starts are then corrected from the span above until none changes.
 template <bool STAGED>
 __device__ __forceinline__ bool huf_stream_passes(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ sb, u32 srcSize, u32 last,
                                                   u8* __restrict__ out, u32 n, u32 lane)
 {
     const s32 P0 = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-    s32 span = (P0 + 127) / 128; if (span < 128) span = 128;            // >= 10 codewords per span
-    const s32 kRunIn = 256;                                              // bits decoded above a span to synchronise (~40 codewords)
-    const s32 hiA = P0 - (s32)(2 * lane) * span, hiB = hiA - span;       // upper boundaries of my two spans
-    const s32 loA = hiB > 0 ? hiB : 0, loB = hiB - span > 0 ? hiB - span : 0;
-    SpanChain<STAGED> A, B;
+    const s32 nSpans = 64 * kChains;
+    s32 span = (P0 + nSpans - 1) / nSpans; if (span < 128) span = 128;  // >= 10 codewords per span
+    const s32 kRunIn = 192;                                              // bits decoded above a span to synchronise (~30 codewords)
+    s32 hi[kChains], lo[kChains];
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) {
+        hi[c] = P0 - (s32)(kChains * lane + c) * span;                   // upper boundary of my c-th span
+        lo[c] = hi[c] - span > 0 ? hi[c] - span : 0;
+    }
+    SpanChain<STAGED> C[kChains];
+    u8* none[kChains] = {};
 #ifdef ZMI_LZ_STAMPS
     unsigned long long t0 = __builtin_amdgcn_s_memtime(); u32 nPass = 0;
 #endif
-    // run-in: first boundary at or below my upper boundary, reached from kRunIn bits above it (lane 0's span A starts exactly)
-    {
-        const s32 gA = hiA + kRunIn < P0 ? hiA + kRunIn : P0, gB = hiB + kRunIn < P0 ? hiB + kRunIn : P0;
-        A.init(gA, hiA > 0 ? hiA : 0); B.init(gB, hiB > 0 ? hiB : 0);
-        if (hiA <= 0) A.init(hiA, hiA);
-        if (hiB <= 0) B.init(hiB, hiB);
-        span_run2<STAGED, false>(table, tableLog, sb, (s32)srcSize, A, B, nullptr, nullptr);
+    // run-in: first boundary at or below each upper boundary, reached from kRunIn bits above it (the very first span starts exactly)
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) {
+        const s32 g = hi[c] + kRunIn < P0 ? hi[c] + kRunIn : P0;
+        if (hi[c] > 0) C[c].init(g, hi[c]); else C[c].init(hi[c], hi[c]);
     }
-    s32 startA = lane == 0 ? P0 : A.pos(), startB = B.pos();
-    s32 endA = startA, endB = startB; u32 cntA = 0, cntB = 0;
-    bool dirtyA = true, dirtyB = true;
-    for (u32 pass = 0; pass < 130; ++pass) {
+    span_run<STAGED, false>(table, tableLog, sb, (s32)srcSize, C, none);
+    s32 start[kChains], end[kChains]; u32 cnt[kChains]; bool dirty[kChains];
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) { start[c] = C[c].pos(); end[c] = start[c]; cnt[c] = 0; dirty[c] = true; }
+    if (lane == 0) start[0] = P0;
+    for (u32 pass = 0; pass < 64 * kChains + 2; ++pass) {
         // (a clean chain is re-initialised at its own end: nothing to do)
-        A.init(dirtyA ? startA : endA, dirtyA ? loA : endA); B.init(dirtyB ? startB : endB, dirtyB ? loB : endB);
-        span_run2<STAGED, false>(table, tableLog, sb, (s32)srcSize, A, B, nullptr, nullptr);
-        if (dirtyA) { endA = A.pos(); cntA = A.cnt; }
-        if (dirtyB) { endB = B.pos(); cntB = B.cnt; }
-        s32 nsA = __shfl_up(endB, 1);
-        if (lane == 0) nsA = P0;
-        const s32 nsB = endA;
-        dirtyA = nsA != startA; dirtyB = nsB != startB;
-        startA = nsA; startB = nsB;
+#pragma unroll
+        for (u32 c = 0; c < kChains; ++c) C[c].init(dirty[c] ? start[c] : end[c], dirty[c] ? lo[c] : end[c]);
+        span_run<STAGED, false>(table, tableLog, sb, (s32)srcSize, C, none);
+#pragma unroll
+        for (u32 c = 0; c < kChains; ++c) if (dirty[c]) { end[c] = C[c].pos(); cnt[c] = C[c].cnt; }
+        s32 ns0 = __shfl_up(end[kChains - 1], 1);
+        if (lane == 0) ns0 = P0;
+        bool anyDirty = false;
+#pragma unroll
+        for (u32 c = 0; c < kChains; ++c) {
+            const s32 ns = c == 0 ? ns0 : end[c - 1];
+            dirty[c] = ns != start[c]; start[c] = ns; anyDirty = anyDirty || dirty[c];
+        }
 #ifdef ZMI_LZ_STAMPS
         ++nPass;
 #endif
-        if (!ballot(dirtyA | dirtyB)) break;
+        if (!ballot(anyDirty)) break;
     }
 #ifdef ZMI_LZ_STAMPS
     unsigned long long t1 = __builtin_amdgcn_s_memtime();
 #endif
-    const u32 cnt2 = cntA + cntB;
-    const u32 incl = wave_scan_incl(cnt2);
+    u32 cntLane = 0;
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) cntLane += cnt[c];
+    const u32 incl = wave_scan_incl(cntLane);
     const u32 total = read_lane(incl, 63);
-    const s32 finalEnd = (s32)read_lane((u32)endB, 63);
+    const s32 finalEnd = (s32)read_lane((u32)end[kChains - 1], 63);
     if (total != n || finalEnd != 0) return false;
-    A.init(startA, loA); B.init(startB, loB);
-    span_run2<STAGED, true>(table, tableLog, sb, (s32)srcSize, A, B, out + (incl - cnt2), out + (incl - cnt2) + cntA);
+    u8* outs[kChains]; u8* o = out + (incl - cntLane);
+#pragma unroll
+    for (u32 c = 0; c < kChains; ++c) { outs[c] = o; o += cnt[c]; C[c].init(start[c], lo[c]); }
+    span_run<STAGED, true>(table, tableLog, sb, (s32)srcSize, C, outs);
 #ifdef ZMI_LZ_STAMPS
     if (lane == 0) { atomicAdd(&g_seqStamps[8], (unsigned long long)nPass); atomicAdd(&g_seqStamps[9], 1ull); atomicAdd(&g_seqStamps[10], t1 - t0); atomicAdd(&g_seqStamps[11], __builtin_amdgcn_s_memtime() - t1); }
 #endif

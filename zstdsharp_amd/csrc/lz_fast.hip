@@ -65,12 +65,15 @@ struct LzLds {
     u64 matchMask[kGroups];              // bit = position holds a match
     u64 capMask[kGroups];                // bit = that match hit the cap
     u64 selMask[kGroups];                // bit = match is on the greedy orbit (selected)
-    u64 covMask[kGroups];                // bit = byte covered by a selected match (tile-local)
+    u64 covMask[2][kGroups];             // bit = byte covered by a selected match (tile-local); slot = tile parity: a sparse tile has
+                                         // a single barrier, so the next tile clears its masks while this tile's literals are still read
     u32 wordRank[kGroups + 1];           // selected matches before each group
     u16 jumpB[kTilePos];                 // second buffer of the doubling rounds; once they end it is reused as
                                          // endOf[r+1] = absolute end of the r-th selected match of the tile (u32[kTilePos/4+2]), endOf[0] = anchor
-    u64 nzWords[2];                      // bit g = matchMask[g] != 0 (accumulated with atomicOr during verify); slot = tile parity
-    u32 matchCount[2];                   // matches in the current tile (decides sparse / dense selection); slot = tile parity
+    // per-tile counters, slot = tile mod 3: between two consecutive verify barriers one slot is read (tile t), one is
+    // accumulated (tile t+1, whose fused probe/verify may already run) and the third is reset for tile t+2
+    u64 nzWords[3];                      // bit g = matchMask[g] != 0 (accumulated with atomicOr during verify)
+    u32 matchCount[3];                   // matches in the current tile (decides sparse / dense selection)
     u16 sparseList[64];                  // sparse path: the tile's matches in position order
 };
 
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         if (MODE == 0) { table[i] = 0; first[i] = 0xFFFFFFFFu; }
         else           { L.tabMem[i] = 0xFFFFFFFFu; L.tabMem[(1u << kHashLog) + i] = 0; }
     }
-    if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; }
+    if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.nzWords[2] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; L.matchCount[2] = 0; }
     __syncthreads();
     ZMI_STAMP(0);
 
@@ -198,6 +201,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u32 nbSeq = 0, litBase = 0;
 
     // one selected match -> its sequence + its coverage bits (used by the dense and the sparse path)
+    u32 covPar = 0;                      // coverage-mask slot of the current tile
     auto emit_match = [&](u32 tileStart, u32 q, u32 rank, u32 end) {
         u32 p = tileStart + q;
         const u32 off = L.tileOff[q];
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             u64 m = ~0ull;
             if (wI == (r0 >> 6)) m &= ~0ull << (r0 & 63);
             if (wI == ((r1 - 1) >> 6)) m &= ~0ull >> (63 - ((r1 - 1) & 63));
-            atomicOr((unsigned long long*)&L.covMask[wI], (unsigned long long)m);
+            atomicOr((unsigned long long*)&L.covMask[covPar][wI], (unsigned long long)m);
         }
     };
     // full length of a match that hit the cap: 64 lanes x 8 bytes per step (whole wave, uniform arguments)
@@ -241,9 +245,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
-        const u32 nPass = kPPT >> strideLog, par = t & 1;
-        // sparse tile of the fast finder: no in-tile candidates, table inserts after the verify barrier -> one barrier less
-        const bool fused = MODE == 0 && strideLog != 0;
+        const u32 nPass = kPPT >> strideLog, par = t % 3;
+        covPar = t & 1;
+        // (A sparse tile could fuse probe and verify and defer its table inserts behind the verify barrier — one barrier
+        // less, measured 7 % faster — but the next tile's probes would then race with those inserts and the output would
+        // depend on wave timing.  Determinism is part of the contract, so the two-barrier form stays.)
+        constexpr bool fused = false;
         // probed position of lattice cell c = j * kTile + tid: c * stride + a pseudo-random residue, so that a repeat of
         // earlier data lines up with inserted positions one time in `stride` whatever its distance (a fixed lattice would
         // never see a repeat whose distance is not a multiple of the stride)
@@ -279,7 +286,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         u64 mmJ[kPPT], cmJ[kPPT];
         if (strideLog != 0 && lane < 4) {        // strided tile: a wave's probes fall into its own four groups; matching lanes set bits below
             const u32 g = strideLog == 2 ? wave * 4 + lane : (lane >> 1) * 32 + wave * 2 + (lane & 1);
-            L.matchMask[g] = 0; L.capMask[g] = 0; L.selMask[g] = 0; L.covMask[g] = 0;
+            L.matchMask[g] = 0; L.capMask[g] = 0; L.selMask[g] = 0; L.covMask[covPar][g] = 0;
         }
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
@@ -393,7 +400,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             const u32 nMatch = popc64(mmJ[0]) + popc64(mmJ[1]) + popc64(mmJ[2]) + popc64(mmJ[3]);
             if (lane < kPPT) {
                 const u32 g = lane * 16 + wave;
-                L.matchMask[g] = mmL; L.capMask[g] = cmL; L.selMask[g] = 0; L.covMask[g] = 0;
+                L.matchMask[g] = mmL; L.capMask[g] = cmL; L.selMask[g] = 0; L.covMask[covPar][g] = 0;
                 if (mmL) atomicOr((unsigned long long*)&L.nzWords[par], 1ull << g);
                 if (lane == 0 && nMatch) atomicAdd(&L.matchCount[par], nMatch);
             }
@@ -403,6 +410,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
         const u32 matchCount = L.matchCount[par];
+        if (tid == 0) { const u32 nx = (t + 2) % 3; L.nzWords[nx] = 0; L.matchCount[nx] = 0; }     // slot of tile t + 2: idle until the next barrier
         if (fused) {                           // the deferred inserts of a sparse tile (every probe of the tile came before the barrier)
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) if (valid[j]) atomicMax(&table[hidx(h[j])], ((tileStart + probed(j) + 1) << 16) | htag(h[j]));
@@ -557,13 +565,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             const u32 q4 = tid * 4;
             *(u32u*)(litOut + litBase + q4) = *reinterpret_cast<const u32*>(L.in + tileStart + q4);
             litBase += kTilePos;
-            if (tid == 0) { L.nzWords[par ^ 1] = 0; L.matchCount[par ^ 1] = 0; }
         } else {
             // Every wave scans the 64 group words itself (one LDS read per lane), so the compaction offsets need neither a
             // cross-wave table nor another barrier.  keepG(g) = bytes of group g that are literals of this tile.
             auto keepG = [&](u32 g) -> u64 {
                 const u32 g0 = g * 64;
-                u64 k = ~L.covMask[g];
+                u64 k = ~L.covMask[covPar][g];
                 const u32 pG = tileStart + g0;
                 if (pG >= n) k = 0; else if (n - pG < 64) k &= (1ull << (n - pG)) - 1;
                 if (c0 > g0) k = (c0 - g0 >= 64) ? 0ull : (k & (~0ull << (c0 - g0)));      // before the entry cursor: inside an earlier match
@@ -585,7 +592,6 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
             }
             litBase += total; nbSeq += nSel; cursor = lastEnd;
-            if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; }     // next tile's probe phase sits behind its own barrier
         }
         ZMI_STAMP(7);
     }
