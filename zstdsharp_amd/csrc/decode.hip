@@ -1427,7 +1427,7 @@ struct SpanChain {
     }
 };
 
-constexpr u32 kChains = 4;              // independent lookup chains per lane (adjacent spans of the same stream)
+constexpr u32 kChains = 2;              // independent lookup chains per lane (adjacent spans of the same stream); 4 measured slower (shorter spans, same LDS latency)
 
 // up to 4 symbols of each of the lane's chains, interleaved instruction by instruction; packed symbols in w[], counts in k[]
 template <bool STAGED, bool WRITE>
@@ -1495,7 +1495,7 @@ __device__ __forceinline__ bool huf_stream_passes(const u16* __restrict__ table,
     const s32 P0 = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
     const s32 nSpans = 64 * kChains;
     s32 span = (P0 + nSpans - 1) / nSpans; if (span < 128) span = 128;  // >= 10 codewords per span
-    const s32 kRunIn = 192;                                              // bits decoded above a span to synchronise (~30 codewords)
+    const s32 kRunIn = 256;                                              // bits decoded above a span to synchronise (~40 codewords)
     s32 hi[kChains], lo[kChains];
 #pragma unroll
     for (u32 c = 0; c < kChains; ++c) {
