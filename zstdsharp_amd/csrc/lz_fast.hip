@@ -256,6 +256,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // never see a repeat whose distance is not a multiple of the stride)
         auto probed = [&](u32 j) -> u32 {
             const u32 cI = j * kTile + tid;
+            if (strideLog == 0) return cI;                   // (uniform) dense tile: every position
             return (cI << strideLog) + ((((tileStart >> kTileLog) * kTilePos + cI) * 2654435761u >> 27) & ((1u << strideLog) - 1));
         };
         // ---------------- probe ----------------
