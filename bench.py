@@ -46,7 +46,8 @@ def make_zipf(n, seed, device):
 
 STAGE_KERNEL = {"compress/lz_fast": "lz_kernel", "compress/huf_build": "huf_build_kernel", "compress/huf_encode": "huf_encode_kernel",
                 "compress/seq_encode": "seq_encode_kernel", "compress/gather": "gather_kernel",
-                "decompress/decode_literals": "decode_literals_kernel", "decompress/decode_sequences": "decode_sequences_kernel"}
+                "decompress/decode_literals": ("decode_literals_compact_kernel", "decode_literals_kernel", "decode_literals_sync_kernel"),
+                "decompress/decode_sequences": "decode_sequences_kernel"}
 
 
 def pmc_traffic(stage, size_mib, kind, level):
@@ -62,9 +63,14 @@ def pmc_traffic(stage, size_mib, kind, level):
         w = d["bench_line_under_profiler"]["config"]["workload"]
         if not (w.startswith(f"{size_mib} MiB") and ("Zipf" in w) == (kind == "zipf") and f"level {level}" in w):
             return None, None
-        for k, v in d["kernels"].items():
-            if k.startswith(STAGE_KERNEL[stage]) and v.get("fetch_corrected") is not None and v.get("write") is not None:
-                if STAGE_KERNEL[stage] == "lz_kernel" and not k.startswith("lz_kernel<" + ("0" if level <= 2 else "1" if level <= 4 else "2")):
+        names = STAGE_KERNEL[stage] if isinstance(STAGE_KERNEL[stage], tuple) else (STAGE_KERNEL[stage],)
+        for name in names:                       # (the literal decoder has three forms; the profile holds the one that ran)
+            for k, v in d["kernels"].items():
+                if not k.startswith(name) or v.get("fetch_corrected") is None or v.get("write") is None:
+                    continue
+                if name == "lz_kernel" and not k.startswith("lz_kernel<" + ("0" if level <= 2 else "1" if level <= 4 else "2")):
+                    continue
+                if v["fetch_corrected"] + v["write"] < 1e6:
                     continue
                 return round((v["fetch_corrected"] + v["write"]) / 1e9, 4), os.path.basename(files[-1])
     except Exception:

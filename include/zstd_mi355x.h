@@ -99,7 +99,8 @@ size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* dctx, void* hipStream);
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* cctx, unsigned chunksPerPass);
 
 /* literal (Huffman) decoder: 0 = chosen by frame count (default), 1 = serial, 4 lanes per frame (highest throughput when
- * thousands of frames are in flight), 2 = self-synchronising, 256 lanes per frame (lowest latency per frame) */
+ * thousands of frames are in flight), 2 = self-synchronising, 256 lanes per frame (lowest latency per frame),
+ * 3 = serial with compact tables (2 KiB + pair table per frame: twice the frames in flight) */
 size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* dctx, unsigned mode);
 
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */

@@ -31,9 +31,10 @@ def ctxs(gpu_lib):
     c.Dispose(); d.Dispose()
 
 
-@pytest.fixture(scope="module", params=[1, 2], ids=["serial-literals", "selfsync-literals"])
+@pytest.fixture(scope="module", params=[1, 2, 3], ids=["serial-literals", "selfsync-literals", "compact-literals"])
 def forced_decoder(gpu_lib, request):
-    """Both literal decoders (the default picks one by frame count): 1 = 4 lanes per frame, 2 = 256 lanes per frame."""
+    """Every literal decoder (the default picks one by frame count): 1 = 4 lanes per frame with 4 KiB tables, 2 = 256 lanes
+    per frame, 3 = 4 lanes per frame with compact (2 KiB + pairs) tables."""
     d = z.Decompressor()
     assert gpu_lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, request.param) == 0
     yield d

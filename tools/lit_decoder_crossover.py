@@ -14,7 +14,7 @@ for mib in (1, 4, 16, 64, 128, 256, 384, 512, 1024):
     cs = lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), n)
     lib.ZSTDMI_DCtx_setProfiling(d.dctx, 1)
     row = []
-    for mode in (1, 2):
+    for mode in (1, 2, 3):
         lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, mode)
         best = 1e9
         for _ in range(3):
@@ -23,5 +23,5 @@ for mib in (1, 4, 16, 64, 128, 256, 384, 512, 1024):
             t = {names[i].decode(): ms[i] for i in range(k)}
             best = min(best, t["decode_literals"])
         row.append(best)
-    print(f"{mib:5d} MiB  frames {n >> 16:6d}  serial {row[0]:8.3f} ms   selfsync {row[1]:8.3f} ms", flush=True)
+    print(f"{mib:5d} MiB  frames {n >> 16:6d}  serial {row[0]:8.3f} ms   selfsync {row[1]:8.3f} ms   compact {row[2]:8.3f} ms", flush=True)
     c.Dispose(); d.Dispose()

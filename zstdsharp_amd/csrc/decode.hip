@@ -770,6 +770,203 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
     return 0;
 }
 
+// =====================================================================================================================
+// Literal decoder, serial form, COMPACT tables: what bounds the serial form is LDS (a 4 KiB table per frame admits 32
+// frames per CU, so 16 384 frames take two rounds).  Here the table is indexed by at most 10 bits (2 KiB); for tableLog 11
+// the longest codes (weight 1) come in pairs that share a 10-bit prefix: their entry is an escape (0xF000 | pair) and one
+// more bit picks the symbol out of `sorted`, the list of symbols in (weight, symbol) order whose head IS the pair table.
+// 2.4 KiB per frame -> 64 frames per CU -> one round.  Same acceptance as the other forms; tableLog 12 goes the slow way.
+// =====================================================================================================================
+struct CompactLds {
+    u16 huf[1024];              // byte | nbBits << 8, or 0xF000 | pair index.  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
+    u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded; entries 2k, 2k+1 = pair k when tableLog = 11
+    u32 classStart[14];         // first index (in the tableLog-bit table) of weight class w; [tableLog + 1] = table size
+    u32 classFirst[14];         // index into sorted[] of the first symbol of class w
+    u32 meta[4];
+};
+
+__device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ table, const u8* __restrict__ sorted, u32 tableLog,
+                                                    const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
+{
+    if (srcSize < 1) return false;
+    const u32 idxBits = tableLog > 10 ? 10u : tableLog;
+    s32 remaining; u32 i = 0;
+    auto lookup = [&](u32 top32) -> u32 {                 // top32 = the next 32 stream bits
+        u32 e = table[top32 >> (32 - idxBits)];
+        if (e >= 0xF000u) e = (u32)sorted[2 * (e & 0xFFFu) + ((top32 >> 21) & 1u)] | (11u << 8);
+        return e;
+    };
+    if (srcSize >= 16) {
+        s32 ptr = (s32)srcSize - 8;
+        u64 cont = readLE64(src + ptr);
+        u64 raw = readLE64(src + ptr - 8); s32 lp = ptr - 8;
+        const u32 last = (u32)(cont >> 56);
+        if (!last) return false;
+        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+        u32 consumed = 64u - (u32)(remaining - 8 * ptr);
+#define ZMI_HUF_STEPC(word)                                                                                        \
+        {                                                                                                           \
+            u32 e;                                                                                                  \
+            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word = e & 0xFFu;                      \
+            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word |= (e & 0xFFu) << 8;              \
+            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word |= (e & 0xFFu) << 16;             \
+            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word |= (e & 0xFFu) << 24;             \
+            const u64 lower = lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0);                            \
+            const u32 k = consumed >> 3;                                                                            \
+            cont = (cont << (8 * k)) | (k ? (lower >> (64 - 8 * k)) : 0);                                           \
+            ptr -= (s32)k; consumed -= 8 * k;                                                                       \
+            lp = ptr - 8;                                                                                           \
+            raw = readLE64(src + (lp > 0 ? lp : 0));                                                                \
+        }
+        while (i + 32 <= n) {
+            u32 w0, w1, w2, w3, w4, w5, w6, w7;
+            ZMI_HUF_STEPC(w0) ZMI_HUF_STEPC(w1) ZMI_HUF_STEPC(w2) ZMI_HUF_STEPC(w3)
+            ZMI_HUF_STEPC(w4) ZMI_HUF_STEPC(w5) ZMI_HUF_STEPC(w6) ZMI_HUF_STEPC(w7)
+            u32u* o = (u32u*)(out + i);
+            o[0] = w0; o[1] = w1; o[2] = w2; o[3] = w3; o[4] = w4; o[5] = w5; o[6] = w6; o[7] = w7;
+            i += 32;
+        }
+        while (i + 4 <= n) {
+            u32 w;
+            ZMI_HUF_STEPC(w)
+            *(u32u*)(out + i) = w;
+            i += 4;
+        }
+#undef ZMI_HUF_STEPC
+        remaining = 8 * ptr + 64 - (s32)consumed;
+    } else {
+        const u32 last = src[srcSize - 1];
+        if (!last) return false;
+        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+    }
+    if (i < n && remaining > 0) {
+        BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
+        while (i < n) { const u32 e = lookup(bd.peek(11) << 21); bd.pos -= (s32)(e >> 8); out[i++] = (u8)e; }
+        remaining = bd.pos;
+    }
+    return i == n && remaining == 0;
+}
+
+// One frame on the 4 lanes of a quad (compact tables).  Returns an error code, or 0xFFFF to ask for the slow path.
+__device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 ql)
+{
+    const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
+    u32 ip = h.headerSize, litOff = 0;
+    bool haveTable = false; u32 tableLog = 0;
+    for (;;) {
+        if (fd.srcSize - ip < 3) return kErrSrcSizeWrong;
+        const u32 bh = readLE24(fsrc + ip);
+        const u32 last = bh & 1, type = (bh >> 1) & 3, bsz = bh >> 3;
+        ip += 3;
+        if (type == 3) return kErrCorruption;
+        if (type == 1) { if (1 > fd.srcSize - ip) return kErrSrcSizeWrong; ip += 1; }
+        else {
+            if (bsz > fd.srcSize - ip) return kErrSrcSizeWrong;
+            if (type == 2) {
+                if (bsz >= kBlockMax) return kErrSrcSizeWrong;
+                if (bsz < 3) return kErrCorruption;
+                const u8* const b = fsrc + ip;
+                const LitHeader lh = parse_lit_header(b, bsz);
+                if (lh.err) return lh.err;
+                if (lh.type >= 2) {
+                    if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
+                    const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
+                    if (lh.type == 2) {
+                        u8* const weights = reinterpret_cast<u8*>(Q.huf + 896);     // top 256 B of the table area until the fill
+                        if (ql == 0) {
+                            QuadScratch sc;
+                            sc.weights = weights; sc.norm = reinterpret_cast<s16*>(Q.huf); sc.symbolNext = Q.huf + 256;
+                            sc.wNewState = Q.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(Q.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(Q.huf + 608);
+                            u32 nbSymbols = 0, tl = 0;
+                            const u32 hs = huf_read_stats(sc, hsrc, hlen, &nbSymbols, &tl);
+                            if (hs && tl <= 11) {          // class extents (HUF_readDTableX1) and the symbols in (weight, symbol) order
+                                for (u32 w = 0; w < 14; w++) { Q.classStart[w] = 0; Q.classFirst[w] = 0; }
+                                for (u32 n = 0; n < nbSymbols; n++) Q.classFirst[weights[n]]++;             // counts, for now
+                                u32 idx = 0, first = 0;
+                                for (u32 w = 1; w <= tl; w++) {
+                                    const u32 cnt = Q.classFirst[w];
+                                    Q.classStart[w] = idx; Q.classFirst[w] = first;
+                                    idx += cnt << (w - 1); first += cnt;
+                                }
+                                Q.classStart[tl + 1] = idx; Q.classFirst[tl + 1] = first;
+                                // running cursors in classFirst[w] while placing; restored afterwards from the class sizes
+                                for (u32 n = 0; n < nbSymbols; n++) { const u32 w = weights[n]; if (w) Q.sorted[Q.classFirst[w]++] = (u8)n; }
+                                for (u32 w = tl; w >= 1; w--) Q.classFirst[w] = w == 1 ? 0u : Q.classFirst[w - 1];   // cursor of w-1 ended where class w begins
+                            }
+                            Q.meta[0] = hs; Q.meta[1] = nbSymbols; Q.meta[2] = tl;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        const u32 hs = Q.meta[0]; tableLog = Q.meta[2];
+                        if (!hs || hs >= hlen) return kErrCorruption;
+                        if (tableLog > 11) return 0xFFFFu;
+                        {   // table fill by the quad's 4 lanes, one symbol of `sorted` at a time
+                            const u32 nSorted = Q.classFirst[tableLog + 1];
+                            const u32 drop = tableLog > 10 ? 1u : 0u;          // 11-bit codes: the table is indexed by the upper 10 bits
+                            for (u32 k = ql; k < nSorted; k += 4) {
+                                u32 w = 1;
+                                for (u32 cw = 2; cw <= tableLog; ++cw) if (Q.classFirst[cw] <= k) w = cw;
+                                const u32 start = Q.classStart[w] + ((k - Q.classFirst[w]) << (w - 1));     // index in the tableLog-bit table
+                                const u32 sym = Q.sorted[k];
+                                if (drop && w == 1) { if (!(start & 1)) Q.huf[start >> 1] = (u16)(0xF000u | (start >> 1)); continue; }
+                                const u32 len = ((1u << w) >> 1) >> drop, st = start >> drop;
+                                const u32 e = sym | ((tableLog + 1 - w) << 8);
+                                if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
+                                else for (u32 u = 0; u < len; u++) Q.huf[st + u] = (u16)e;
+                            }
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                        haveTable = true;
+                        hsrc += hs; hlen -= hs;
+                    } else if (!haveTable) return kErrDictionaryCorrupted;
+                    u8* const dst = litOut + litOff;
+                    bool ok = true;
+                    if (lh.single) {
+                        if (ql == 0) ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, hsrc, hlen, dst, lh.litSize);
+                    } else {
+                        if (hlen < 10) return kErrCorruption;
+                        const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
+                        const u32 seg = (lh.litSize + 3) / 4;
+                        if (6 + l1 + l2 + l3 > hlen) return kErrCorruption;
+                        if (seg * 3 > lh.litSize) return kErrCorruption;
+                        const u32 l4 = hlen - 6 - l1 - l2 - l3;
+                        const u32 so = ql == 0 ? 6 : ql == 1 ? 6 + l1 : ql == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
+                        const u32 sl = ql == 0 ? l1 : ql == 1 ? l2 : ql == 2 ? l3 : l4;
+                        const u32 on = ql < 3 ? seg : lh.litSize - 3 * seg;
+                        ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, hsrc + so, sl, dst + ql * seg, on);
+                    }
+                    if (ql == 0) Q.meta[3] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    if (!ok) Q.meta[3] = 1;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    if (Q.meta[3]) return kErrCorruption;
+                    litOff += lh.litSize;
+                }
+            }
+            ip += bsz;
+        }
+        if (last) break;
+    }
+    return 0;
+}
+
+__global__ __launch_bounds__(64) void decode_literals_compact_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
+                                                                     u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
+                                                                     u8* __restrict__ slowFlags)
+{
+    __shared__ CompactLds Qs[kQuads];
+    const u32 lane = threadIdx.x, q = lane >> 2, ql = lane & 3;
+    const u32 f = blockIdx.x * kQuads + q;
+    if (q >= kQuads || f >= nFrames) return;
+    const FrameDesc fd = frames[f];
+    if (ql == 0) slowFlags[f] = 0;
+    if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (ql == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
+    const u32 err = quad_decode_literals_c(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql);
+    if (ql == 0) {
+        if (err == 0xFFFFu) slowFlags[f] = 1;
+        else if (err) atomicCAS(frameErr, 0u, err);
+    }
+}
+
 __global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
                                                              u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
                                                              u8* __restrict__ slowFlags)
@@ -1703,13 +1900,26 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
     if (err && tid == 0) atomicCAS(frameErr, 0u, err);
 }
 
-// Two literal decoders.  The serial one (4 lanes per frame) has the fewest instructions per symbol and wins once there
-// are enough frames to fill the chip (one round = 8192 frames: 1.0-1.7 ms for 16..8192 frames, 3.3 ms for 16384); the
-// self-synchronising one (256 lanes per frame) takes 0.15 ms up to 256 frames and 0.25 ms per 1000 frames beyond.  mode: 0 = choose by frame count, 1 = serial, 2 = self-synchronising.
+// Three literal decoders (tools/lit_decoder_crossover.py, MI355X, 64 KiB Zipf frames):
+//   serial   (4 lanes per frame, 4 KiB table):  32 frames per CU; a round of 8192 frames takes 1.1-1.7 ms;
+//   compact  (4 lanes per frame, 2 KiB table + pair table): 64 frames per CU; a round of 16 384 frames takes 1.8-2.7 ms;
+//   selfsync (256 lanes per frame): 0.15 ms up to 256 frames, 0.25 ms per 1000 frames beyond.
+// mode: 0 = choose by frame count, 1 = serial, 2 = self-synchronising, 3 = compact.
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
                             u8* slowFlags, u32 mode, hipStream_t stream)
 {
-    const bool sync = mode == 2 || (mode == 0 && nFrames <= 6144);      // measured crossover ~6100 frames (tools/lit_decoder_crossover.py)
+    if (mode == 0) {
+        static int cus[64] = {};                     // per device
+        int dev = 0; (void)hipGetDevice(&dev);
+        if (!cus[dev & 63]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cus[dev & 63] = n > 0 ? n : 256; }
+        const u32 roundS = (u32)cus[dev & 63] * 32u, roundC = roundS * 2u;
+        if (nFrames <= roundS * 3u / 4u) mode = 2;
+        else {
+            const float tS = (float)((nFrames + roundS - 1) / roundS) * 1.7f, tC = (float)((nFrames + roundC - 1) / roundC) * 2.7f;
+            mode = tC < tS ? 3u : 1u;
+        }
+    }
+    const bool sync = mode == 2;
     if (sync) {
         static bool attrSet[64] = {};               // per device
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1717,7 +1927,8 @@ void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames,
         hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nFrames), dim3(256), sizeof(SyncLds), stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity);
         return;
     }
-    hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
+    if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
+    else           hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
 }
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,

@@ -687,7 +687,7 @@ size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kEr
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
-size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
+size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 3) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* c, unsigned chunks) { if (!c || chunks == 0 || chunks > (1u << 20)) return ZERR(kErrParameterOutOfBound); c->passChunks = chunks; return 0; }
 size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* c, int en) { if (!c) return ZERR(kErrGeneric); c->timer.enabled = en != 0; return 0; }
 size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* d, int en) { if (!d) return ZERR(kErrGeneric); d->timer.enabled = en != 0; return 0; }
