@@ -103,6 +103,7 @@ u64 zso_xxh64(const void* data, size_t len, u64 seed);
 
 /* decoder (zso_dec.c) */
 size_t zso_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+size_t zso_decompress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* dict, size_t dictSize);
 u64    zso_decompressBound(const void* src, size_t srcSize);
 u64    zso_getFrameContentSize(const void* src, size_t srcSize);
 size_t zso_findFrameCompressedSize(const void* src, size_t srcSize);

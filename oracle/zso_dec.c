@@ -334,6 +334,7 @@ typedef struct {
     int llValid, ofValid, mlValid;
     zso_huf_dtable huf;
     u32 rep[3];
+    const u8* dict; size_t dictSize;  /* raw-content dictionary = history in front of every frame (ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771) */
 } zso_frame_state;
 
 /* ZSTD_buildSeqTable, U/ZstdDecompressBlock.cs:1746-1840.  Returns bytes consumed. */
@@ -491,7 +492,16 @@ static size_t zso_decodeBlock(zso_frame_state* fs, u8* const dstStart, u8* op, u
                     if (litLength > (size_t)(litEnd - litPtr)) return ZSO_ERR(corruption_detected);
                     if (litLength + matchLength > (size_t)(oend - op)) return ZSO_ERR(dstSize_tooSmall);
                     memcpy(op, litPtr, litLength); op += litLength; litPtr += litLength;
-                    if (offset > (size_t)(op - dstStart)) return ZSO_ERR(corruption_detected);
+                    if (offset > (size_t)(op - dstStart)) {
+                        /* the match starts in the dictionary (ZSTD_execSequence's extDict branch, :2223-2250): the dictionary's
+                           end is virtually contiguous with the start of the frame's output */
+                        size_t const back = offset - (size_t)(op - dstStart);
+                        size_t n1;
+                        if (back > fs->dictSize) return ZSO_ERR(corruption_detected);
+                        n1 = back < matchLength ? back : matchLength;
+                        memcpy(op, fs->dict + fs->dictSize - back, n1);
+                        op += n1; matchLength -= n1;
+                    }
                     {   const u8* m = op - offset; size_t k;
                         for (k = 0; k < matchLength; k++) op[k] = m[k];   /* byte-wise: overlap semantics */
                         op += matchLength;
@@ -677,12 +687,22 @@ static size_t zso_decompressFrame(u8* dst, size_t dstCapacity, const u8** srcPtr
 /* ZSTD_decompressMultiFrame, U/ZstdDecompress.cs:1216-1315 */
 size_t zso_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
+    return zso_decompress_usingDict(dst, dstCapacity, src, srcSize, NULL, 0);
+}
+
+/* ZSTD_decompress_usingDict with a RAW-CONTENT dictionary (no magic: ZSTD_decompress_insertDictionary falls through to
+ * ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771, 1909-1931).  A dictionary that starts with the dictionary magic
+ * carries entropy tables, which this oracle does not restate: refused. */
+size_t zso_decompress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* dict, size_t dictSize)
+{
     const u8* ip = (const u8*)src; u8* op = (u8*)dst;
     int moreThan1Frame = 0;
     zso_frame_state* fs = (zso_frame_state*)malloc(sizeof *fs);
     u8* litBuf = (u8*)malloc(ZSO_BLOCKSIZE_MAX + 64);
     size_t result = 0;
     if (!fs || !litBuf) { free(fs); free(litBuf); return ZSO_ERR(memory_allocation); }
+    if (dictSize >= 8 && zso_readLE32(dict) == 0xEC30A437u) { free(fs); free(litBuf); return ZSO_ERR(parameter_unsupported); }
+    fs->dict = (const u8*)dict; fs->dictSize = dict ? dictSize : 0;
     while (srcSize >= 5) {
         u32 const magic = zso_readLE32(ip);
         if ((magic & 0xFFFFFFF0u) == ZSO_MAGIC_SKIPPABLE) {

@@ -1303,9 +1303,17 @@ static size_t zso_blockCompressor(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], 
     return zso_compressBlock_fast(ms, ss, rep, src, srcSize);
 }
 
-size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksumFlag)
+/* prefixLen > 0: the `prefixLen` bytes in front of `src` are a raw-content dictionary, loaded the way
+ * ZSTD_loadDictionaryContent does for the fast strategy (window extended over it, ZSTD_fillHashTable with dtlm_fast,
+ * U/ZstdCompress.cs:5126-5237, U/ZstdFast.cs:9-46) with the input contiguous behind it, so that the noDict block
+ * compressor sees it as plain history.  This is the reference's prefix/raw-dictionary semantics, not the CDict
+ * attach/copy path `ZSTD_CCtx_loadDictionary` + `ZSTD_compress2` would take (dictMatchState / extDict finders, which
+ * this oracle does not restate): the frames are valid dictionary frames for DECODER tests; their bytes are
+ * "parity unpinned" (the reference holds no dictionary fixtures — its tests train dictionaries at run time). */
+static size_t zso_compress_internal(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksumFlag,
+                                    size_t prefixLen)
 {
-    zso_cparams const cp = zso_getCParams(level, srcSize);
+    zso_cparams const cp = zso_getCParams(level, srcSize + prefixLen);
     u8* const ostart = (u8*)dst; u8* op = ostart; const u8* ip = (const u8*)src; size_t remaining = srcSize;
     size_t blockSize = (size_t)1 << cp.windowLog; size_t result;
     zso_mstate ms; zso_seqstore ss; zso_bstate *prev, *next; int isFirstBlock = 1, wroteBlock = 0;
@@ -1314,16 +1322,22 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
     /* greedy/lazy use the row-hash finder only when windowLog > 14 (ZSTD_resolveRowMatchFinderMode, U/ZstdCompress.cs:221-252);
        the hash-chain finder of the small-window tiers is not restated: say so, never substitute */
     if (cp.strategy >= ZSO_greedy && cp.windowLog <= 14) return ZSO_ERR(parameter_unsupported);
+    if (prefixLen && cp.strategy != ZSO_fast) return ZSO_ERR(parameter_unsupported);
     {   size_t const h = zso_writeFrameHeader(op, dstCapacity, cp.windowLog, srcSize, checksumFlag);
         if (zso_isError(h)) return h;
         op += h; dstCapacity -= h;
     }
-    ms.cp = cp; ms.base = ip - 2; ms.dictLimit = ms.lowLimit = 2;
+    ms.cp = cp; ms.base = ip - prefixLen - 2; ms.dictLimit = ms.lowLimit = 2;
     ms.hashTable = (u32*)calloc((size_t)1 << cp.hashLog, sizeof(u32));
     ms.chainTable = (u32*)calloc((size_t)1 << cp.chainLog, sizeof(u32));
     ms.tagTable = (u16*)calloc((size_t)1 << cp.hashLog, sizeof(u16));
     {   u32 const sl = cp.searchLog, rowLog = sl < 4 ? 4 : (sl > 6 ? 6 : sl); ms.rowHashLog = cp.hashLog - rowLog; }
     ms.nextToUpdate = 2; memset(ms.hashCache, 0, sizeof ms.hashCache);
+    if (prefixLen > 8) {            /* ZSTD_fillHashTable(ms, dictEnd, ZSTD_dtlm_fast) */
+        const u8* p = ms.base + ms.nextToUpdate; const u8* const fend = ip - 8;
+        for (; p + 3 < fend + 2; p += 3) ms.hashTable[zso_hashPtr(p, cp.hashLog, cp.minMatch)] = (u32)(p - ms.base);
+        ms.nextToUpdate = (u32)(ip - ms.base);
+    }
     seqstore_alloc(&ss, blockSize);
     prev = (zso_bstate*)malloc(sizeof *prev); next = (zso_bstate*)malloc(sizeof *next);
     bstate_reset(prev); bstate_reset(next);
@@ -1385,6 +1399,25 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
 done:
     free(ms.hashTable); free(ms.chainTable); free(ms.tagTable); seqstore_free(&ss); free(prev); free(next);
     return result;
+}
+
+size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksumFlag)
+{
+    return zso_compress_internal(dst, dstCapacity, src, srcSize, level, checksumFlag, 0);
+}
+
+size_t zso_compress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                              const void* dict, size_t dictSize, int level, int checksumFlag)
+{
+    u8* buf; size_t r;
+    if (dict == NULL || dictSize < 8) return zso_compress(dst, dstCapacity, src, srcSize, level, checksumFlag);   /* :5469-5477 */
+    if (zso_readLE32(dict) == 0xEC30A437u) return ZSO_ERR(parameter_unsupported);     /* formatted dictionary: entropy tables not restated */
+    buf = (u8*)malloc(dictSize + srcSize + 8);
+    if (!buf) return ZSO_ERR(memory_allocation);
+    memcpy(buf, dict, dictSize); memcpy(buf + dictSize, src, srcSize); memset(buf + dictSize + srcSize, 0, 8);
+    r = zso_compress_internal(dst, dstCapacity, buf + dictSize, srcSize, level, checksumFlag, dictSize);
+    free(buf);
+    return r;
 }
 
 size_t zso_compress_chunked(void* dst, size_t dstCapacity, const void* src, size_t srcSize,

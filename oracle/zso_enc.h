@@ -25,6 +25,11 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
 size_t zso_compress_chunked(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                             int level, int checksumFlag, size_t chunkSize);
 
+/* Raw-content dictionary as history in front of the input (fast strategy only; see zso_enc.c for what this restates).
+ * Generator of dictionary frames for decoder tests; "parity unpinned". */
+size_t zso_compress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
+                              const void* dict, size_t dictSize, int level, int checksumFlag);
+
 /* Stage hooks for kernel-level parity tests (SURVEY.md §8 a-4 … a-11). */
 
 /* a-4: run the level's block match finder over ONE block with fresh state (rep = {1,4,8}, empty table).

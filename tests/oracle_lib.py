@@ -29,6 +29,8 @@ def lib():
         o = ctypes.CDLL(build())
         sz, vp, ci = ctypes.c_size_t, ctypes.c_void_p, ctypes.c_int
         o.zso_decompress.restype, o.zso_decompress.argtypes = sz, [vp, sz, vp, sz]
+        o.zso_decompress_usingDict.restype, o.zso_decompress_usingDict.argtypes = sz, [vp, sz, vp, sz, vp, sz]
+        o.zso_compress_usingDict.restype, o.zso_compress_usingDict.argtypes = sz, [vp, sz, vp, sz, vp, sz, ci, ci]
         o.zso_decompressBound.restype, o.zso_decompressBound.argtypes = ctypes.c_uint64, [vp, sz]
         o.zso_findFrameCompressedSize.restype, o.zso_findFrameCompressedSize.argtypes = sz, [vp, sz]
         o.zso_compress.restype, o.zso_compress.argtypes = sz, [vp, sz, vp, sz, ci, ci]
@@ -53,10 +55,22 @@ def err_code(v: int) -> int:
     return (1 << 64) - v if is_error(v) else 0
 
 
-def decompress(data: bytes, cap: int):
-    """-> bytes, or a negative error code"""
+def decompress(data: bytes, cap: int, dict_bytes: bytes = None):
+    """-> bytes, or a negative error code.  dict_bytes: a raw-content dictionary"""
     buf = ctypes.create_string_buffer(max(cap, 1))
-    n = lib().zso_decompress(buf, cap, data, len(data))
+    if dict_bytes:
+        n = lib().zso_decompress_usingDict(buf, cap, data, len(data), dict_bytes, len(dict_bytes))
+    else:
+        n = lib().zso_decompress(buf, cap, data, len(data))
+    return -err_code(n) if is_error(n) else buf.raw[:n]
+
+
+def compress_dict(data: bytes, dict_bytes: bytes, level: int = 1, checksum: int = 0):
+    """one frame whose matches may reach into the raw-content dictionary (fast strategy only)"""
+    o = lib()
+    cap = o.zso_compressBound(len(data)) + 64
+    buf = ctypes.create_string_buffer(cap)
+    n = o.zso_compress_usingDict(buf, cap, data, len(data), dict_bytes, len(dict_bytes), level, checksum)
     return -err_code(n) if is_error(n) else buf.raw[:n]
 
 
