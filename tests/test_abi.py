@@ -66,8 +66,11 @@ def test_parameters_without_a_device():
     with pytest.raises(ZstdException) as e:
         c.SetParameter(400, 2)                             # nbWorkers: unsupported, as in the reference (U/ZstdCompress.cs:1064-1072)
     assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_unsupported
-    with pytest.raises(ZstdException):
-        c.LoadDictionary(b"some dictionary bytes")
+    c.LoadDictionary(b"some dictionary bytes")             # raw content: kept on the host until a compression needs it
+    c.LoadDictionary(None)
+    with pytest.raises(ZstdException) as e:
+        c.LoadDictionary(bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(64))      # formatted (trained) dictionaries are out of scope
+    assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_unsupported
     c.Dispose()
     with pytest.raises(RuntimeError):
         c.Wrap(b"x")

@@ -1,0 +1,235 @@
+"""raw-content dictionaries (`Compressor.LoadDictionary` / `Decompressor.LoadDictionary`,
+S/Compressor.cs:43-56, S/Decompressor.cs:36-48).  Cases follow the dictionary halves of T/ZstdNetTests.cs; the reference
+builds its dictionaries with the trainer (formatted dictionaries, out of scope, refused by the library), so the
+dictionaries here are raw content — which `ZSTD_CCtx_loadDictionary` accepts as such when the magic is absent.
+Checker: the oracle's decoder with the same dictionary (tests only); decoder inputs: the oracle's dictionary frames."""
+import io
+
+import numpy as np
+import pytest
+
+import datagen
+import zstdsharp_amd as z
+from zstdsharp_amd.errors import ZstdException
+from zstdsharp_amd.streams import CompressionStream, DecompressionStream
+
+pytestmark = pytest.mark.gpu
+
+_WORDS = None
+
+
+def words_text(n: int, seed: int) -> bytes:
+    """text over a fixed vocabulary: a dictionary built from the same vocabulary shares most of its strings"""
+    global _WORDS
+    if _WORDS is None:
+        r = np.random.default_rng(99)
+        _WORDS = [bytes(r.integers(97, 123, size=int(r.integers(3, 11))).astype(np.uint8)) for _ in range(400)]
+    r = np.random.default_rng(seed)
+    out = bytearray()
+    while len(out) < n:
+        out += _WORDS[int(r.integers(0, len(_WORDS)))] + b" "
+    return bytes(out[:n])
+
+
+def build_dictionary(n: int = 20000, seed: int = 5) -> bytes:      # stands in for T/ZstdNetTests.cs BuildDictionary (trained there)
+    return words_text(n, seed)
+
+
+DICT_SIZES = [8, 9, 100, 4095, 4096, 4097, 20000, 32768, 32769, 40000, 61440, 61441, 100000]
+DATA_SIZES = [0, 1, 7, 8, 100, 3000, 4096, 4097, 28000, 32768, 32769, 65536, 70000, 300001]
+
+
+@pytest.fixture(scope="module")
+def pair(gpu_lib):
+    c, d = z.Compressor(1), z.Decompressor()
+    yield c, d
+    c.LoadDictionary(None); d.LoadDictionary(None)
+    c.Dispose(); d.Dispose()
+
+
+@pytest.mark.parametrize("level", [1, 3, 5, 19])
+def test_round_trip_with_dictionary(gpu_lib, oracle, level):
+    """T/ZstdNetTests.cs:19-39 (useDictionary = true) at min/default/max-like levels."""
+    dic = build_dictionary()
+    with z.Compressor(level) as c, z.Decompressor() as d:
+        c.LoadDictionary(dic); d.LoadDictionary(dic)
+        for n in DATA_SIZES:
+            data = words_text(n, n + 11)
+            comp = c.Wrap(data)
+            assert oracle.decompress(comp, n, dic) == data, (level, n)
+            assert d.Unwrap(comp) == data, (level, n)
+
+
+@pytest.mark.parametrize("dict_size", DICT_SIZES)
+def test_dictionary_sizes(pair, oracle, dict_size):
+    """dictionary tail lengths around the tile (4 KiB), the two caps (32 KiB, 60 KiB) and beyond"""
+    c, d = pair
+    dic = build_dictionary(dict_size, dict_size)
+    c.LoadDictionary(dic); d.LoadDictionary(dic)
+    for n in (1, 100, 3000, 5000, 33000, 70001, 200000):
+        for kind in ("words", "zipf"):
+            data = words_text(n, n + dict_size) if kind == "words" else datagen.gen("zipf", n, n)
+            comp = c.Wrap(data)
+            assert oracle.decompress(comp, n, dic) == data, (dict_size, n, kind)
+            assert d.Unwrap(comp) == data, (dict_size, n, kind)
+
+
+def test_decoder_on_oracle_dictionary_frames(gpu_lib, oracle):
+    """the oracle's dictionary frames (matches reaching into the dictionary, 128 KiB blocks, initial repcodes that point
+    into the dictionary) through every literal decoder"""
+    for mode in (0, 1, 2, 3):
+        with z.Decompressor() as d:
+            assert gpu_lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, mode) == 0
+            for dict_size in (8, 1000, 20000, 150000):
+                dic = build_dictionary(dict_size, 3 * dict_size)
+                d.LoadDictionary(dic)
+                for n in (0, 1, 9, 100, 5000, 70000, 300000):
+                    data = words_text(n, n + 1)
+                    for chk in (0, 1):
+                        frame = oracle.compress_dict(data, dic, 1, chk)
+                        assert not isinstance(frame, int)
+                        assert d.Unwrap(frame) == data, (mode, dict_size, n, chk)
+                # several dictionary frames and a plain one in a row
+                parts = [words_text(m, m) for m in (10, 40000, 0, 130000)]
+                blob = b"".join(oracle.compress_dict(p, dic, 1, 1) for p in parts) + oracle.compress(parts[1], 1, 0)
+                assert d.Unwrap(blob) == b"".join(parts) + parts[1]
+
+
+def test_dictionary_match_that_runs_over_into_the_frame(gpu_lib, oracle):
+    """a match starting in the dictionary and continuing, at the same distance, from the start of the frame
+    (U/ZstdDecompressBlock.cs:2223-2250): data = the dictionary's tail repeated"""
+    dic = words_text(5000, 1)
+    for tail in (1, 2, 3, 7, 8, 64, 1000):
+        data = (dic[-tail:] * (3000 // tail + 2))[:3000] + b"#"
+        frame = oracle.compress_dict(data, dic, 1, 1)
+        with z.Decompressor() as d:
+            d.LoadDictionary(dic)
+            assert d.Unwrap(frame) == data, tail
+        with z.Compressor(1) as c, z.Decompressor() as d:
+            c.LoadDictionary(dic); d.LoadDictionary(dic)
+            comp = c.Wrap(data)
+            assert oracle.decompress(comp, len(data), dic) == data, tail
+            assert d.Unwrap(comp) == data, tail
+
+
+def test_decompress_with_dictionary_data_compressed_without_it(pair):
+    """T/ZstdNetTests.cs:76-93"""
+    c, d = pair
+    data = words_text(10000, 3)
+    c.LoadDictionary(None)
+    comp = c.Wrap(data)
+    d.LoadDictionary(build_dictionary())
+    assert d.Unwrap(comp) == data
+
+
+def test_decompress_without_dictionary_throws_on_data_compressed_with_it(pair):
+    """T/ZstdNetTests.cs:95-113"""
+    c, d = pair
+    data = words_text(10000, 4)
+    c.LoadDictionary(build_dictionary())
+    comp = c.Wrap(data)
+    d.LoadDictionary(None)
+    with pytest.raises(ZstdException):
+        d.Unwrap(comp)
+
+
+def test_decompress_with_another_dictionary_throws(gpu_lib):
+    """T/ZstdNetTests.cs:115-134.  Raw dictionaries carry no dictID, so the mismatch shows as an offset beyond the (shorter)
+    dictionary or, with the checksum on, as a checksum error."""
+    data = words_text(10000, 5)
+    with z.Compressor(1) as c, z.Decompressor() as d:
+        c.SetParameter(201, 1)                             # ZSTD_c_checksumFlag
+        c.LoadDictionary(build_dictionary())
+        comp = c.Wrap(data)
+        d.LoadDictionary(b"zstd supports raw-content dictionaries")
+        with pytest.raises(ZstdException):
+            d.Unwrap(comp)
+        d.LoadDictionary(build_dictionary(20000, 77))          # same length, other content
+        with pytest.raises(ZstdException):
+            d.Unwrap(comp)
+
+
+def test_compress_works_better_with_dictionary(gpu_lib):
+    """T/ZstdNetTests.cs:148-164"""
+    data = words_text(3000, 6)
+    for level in (1, 3, 5):
+        with z.Compressor(level) as c:
+            without = c.Wrap(data)
+            c.LoadDictionary(build_dictionary())
+            with_dict = c.Wrap(data)
+        assert len(without) > len(with_dict), level
+    # and on an input of many chunks
+    big = words_text(1 << 20, 8)
+    with z.Compressor(1) as c:
+        without = c.Wrap(big)
+        c.LoadDictionary(build_dictionary())
+        with_dict = c.Wrap(big)
+    assert len(with_dict) < len(without) * 1.02
+
+
+def test_null_dictionary_resets_and_tiny_dictionary_is_ignored(gpu_lib, oracle):
+    """S/Compressor.cs:46-48 (null = no dictionary); dictionaries under 8 bytes are ignored (U/ZstdCompress.cs:5469-5477)"""
+    data = words_text(5000, 9)
+    with z.Compressor(1) as c:
+        plain = c.Wrap(data)
+        c.LoadDictionary(build_dictionary())
+        assert c.Wrap(data) != plain
+        c.LoadDictionary(None)
+        assert c.Wrap(data) == plain
+        c.LoadDictionary(b"1234567")
+        assert c.Wrap(data) == plain
+        assert oracle.decompress(plain, len(data)) == data
+
+
+def test_formatted_dictionary_is_refused(gpu_lib):
+    """a zstd-format dictionary (magic 0xEC30A437: entropy tables, repcodes, dictID) is out of scope: refused on both sides,
+    never half-applied"""
+    formatted = bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(200)
+    with z.Compressor(1) as c, z.Decompressor() as d:
+        with pytest.raises(ZstdException) as e:
+            c.LoadDictionary(formatted)
+        assert e.value.code == 40
+        with pytest.raises(ZstdException) as e:
+            d.LoadDictionary(formatted)
+        assert e.value.code == 40
+        data = words_text(1000, 1)
+        assert d.Unwrap(c.Wrap(data)) == data             # contexts stay usable, without a dictionary
+
+
+def test_frame_naming_a_dictionary_id_is_dictionary_wrong(gpu_lib, oracle):
+    """U/ZstdDecompress.cs:1404-1412: a frame with a dictID the context does not hold -> dictionary_wrong"""
+    frame = bytearray(oracle.compress(b"hello hello hello hello", 1, 0))
+    # rebuild the header with a 1-byte dictID: FHD bit0-1 = 1
+    fhd = frame[4]
+    blob = bytes(frame[:4]) + bytes([fhd | 1, 0x2A]) + bytes(frame[5:])
+    with z.Decompressor() as d:
+        d.LoadDictionary(build_dictionary())
+        with pytest.raises(ZstdException) as e:
+            d.Unwrap(blob, maxDecompressedSize=100)
+        assert e.value.code == 32
+
+
+def test_streaming_with_dictionary(gpu_lib, oracle):
+    """S/CompressionStream.cs:58-62, S/DecompressionStream.cs:58-62"""
+    dic = build_dictionary()
+    data = words_text(200000, 12)
+    tmp = io.BytesIO()
+    with CompressionStream(tmp) as cs:
+        cs.LoadDictionary(dic)
+        cs.Write(data[:70000]); cs.Flush(); cs.Write(data[70000:])
+    blob = tmp.getvalue()
+    assert oracle.decompress(blob, len(data), dic) == data
+    tmp.seek(0)
+    with DecompressionStream(tmp) as ds:
+        ds.LoadDictionary(dic)
+        assert ds.ReadToEnd() == data
+
+
+def test_dictionary_compression_is_deterministic(gpu_lib):
+    dic = build_dictionary(40000, 2)
+    data = words_text(500000, 13) + datagen.gen("zipf", 300000, 1)
+    with z.Compressor(1) as c:
+        c.LoadDictionary(dic)
+        first = c.Wrap(data)
+        for _ in range(3):
+            assert c.Wrap(data) == first

@@ -1119,7 +1119,8 @@ __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | 
 // the batch (ZSTD_execSequence, :2187-2262): output positions by prefix sum, literals (long runs in 16-byte pieces dealt
 // round-robin), matches in dependency rounds.
 __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out,
-                                      const u8* __restrict__ litIn, const u32 lane, u32* actualOut)
+                                      const u8* __restrict__ litIn, const u32 lane, u32* actualOut,
+                                      const u8* __restrict__ dict, const u32 dictSize)
 {
 #define FAIL(code) return (code)
 #ifdef ZMI_LZ_STAMPS
@@ -1255,7 +1256,7 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                     const u32 dLit = op + inclOut - ll - ml;            // where my literals go
                     const u32 dMatch = dLit + ll;                       // where my match goes
                     const u32 sLit = litPos + inclLit - ll;
-                    if (ballot(have && (off > dMatch || off == 0))) FAIL(kErrCorruption);
+                    if (ballot(have && (off > dMatch + dictSize || off == 0))) FAIL(kErrCorruption);
                     // literals: short runs by their own lane; long runs are cut into 16-byte pieces (the last one overlapping the
                     // one before, so every piece is whole) and ALL pieces of the batch are dealt to the lanes round-robin, four
                     // in flight per lane: the copy is paced by bandwidth, not by one load-store round trip per run
@@ -1302,8 +1303,21 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                     // are ready: short ones by their own lane, long ones by the whole wave, then one fence.  The number of
                     // rounds is the depth of the dependency chain, not the number of dependent matches.
                     {
-                        const bool hasMatch = have && ml != 0;
-                        const u32 srcLo = dMatch - off, srcHi = srcLo + (off < ml ? off : ml);
+                        // a match that starts in the dictionary (ZSTD_execSequence's extDict branch, U/ZstdDecompressBlock.cs:2223-2250):
+                        // its first bytes come from the dictionary's tail (read-only, no dependency), the rest is an ordinary
+                        // match at the same distance whose source is the start of the frame
+                        u32 dictN = 0;
+                        if (dictSize) {                                 // uniform
+                            if (have && off > dMatch) {
+                                const u32 back = off - dMatch;
+                                dictN = back < ml ? back : ml;
+                                const u8* ds = dict + (dictSize - back);
+                                for (u32 i = 0; i < dictN; i++) out[dMatch + i] = ds[i];
+                            }
+                        }
+                        const u32 dMatchR = dMatch + dictN, mlR = ml - dictN;      // what remains for the rounds
+                        const bool hasMatch = have && mlR != 0;
+                        const u32 srcLo = dMatchR - off, srcHi = srcLo + (off < mlR ? off : mlR);
                         // earlier lanes whose match output overlaps my source: outputs are laid out in lane order, so they form
                         // a lane interval [jl, jh) found by two binary searches over the (monotone) per-lane bounds
                         const u64 mm = ballot(hasMatch);
@@ -1322,12 +1336,12 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
                         ZMI_SSTAMP(4);
                         while (doneMask != ~0ull) {
                             const bool ready = mine && (dep & ~doneMask) == 0;
-                            const bool longM = ml > 64;
-                            if (ready && !longM) lane_match_copy(out + dMatch, off, ml);
+                            const bool longM = mlR > 64;
+                            if (ready && !longM) lane_match_copy(out + dMatchR, off, mlR);
                             u64 lm = ballot(ready && longM);
                             while (lm) {
                                 const u32 i = ctz64(lm); lm &= lm - 1;
-                                wave_match_copy(out + read_lane(dMatch, i), read_lane(off, i), read_lane(ml, i), lane);
+                                wave_match_copy(out + read_lane(dMatchR, i), read_lane(off, i), read_lane(mlR, i), lane);
                             }
                             const u64 r = ballot(ready);
                             doneMask |= r; mine = mine && !ready;
@@ -1395,7 +1409,8 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
 
 __global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restrict__ src, u64 srcSize, u8* __restrict__ dst, u64 dstCapacity,
                                                               const FrameDesc* __restrict__ frames, u32 nFrames, u32* __restrict__ frameErr,
-                                                              const u8* __restrict__ litScratch, u32* __restrict__ frameActual)
+                                                              const u8* __restrict__ litScratch, u32* __restrict__ frameActual,
+                                                              const u8* __restrict__ dict, u32 dictSize)
 {
     __shared__ SeqLds L;
     const u32 f = blockIdx.x, lane = threadIdx.x;
@@ -1403,7 +1418,7 @@ __global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restri
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
     u32 actual = 0;
-    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane, &actual);
+    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane, &actual, dict, dictSize);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
     if (frameActual && lane == 0) frameActual[f] = err ? 0u : actual;      // only asked for when some frame carries no content size
 }
@@ -1932,9 +1947,11 @@ void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames,
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
 }
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, u32* frameActual, hipStream_t stream)
+                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, hipStream_t stream)
 {
-    hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch, frameActual);
+    // dict: a raw-content dictionary = history in front of EVERY frame (ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771); may be null
+    hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch,
+                       frameActual, dict, dict ? dictSize : 0u);
 }
 
 #ifdef ZMI_LZ_STAMPS

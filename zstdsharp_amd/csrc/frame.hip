@@ -49,7 +49,7 @@ __device__ __forceinline__ void copy_bytes(u8* __restrict__ d, const u8* __restr
 
 __global__ __launch_bounds__(256) void gather_kernel(const u8* __restrict__ src, u64 srcSize, const u8* __restrict__ slots,
                                                      const ChunkMeta* __restrict__ meta, const u64* __restrict__ offsets,
-                                                     u8* __restrict__ dst, u64 dstCapacity)
+                                                     u8* __restrict__ dst, u64 dstCapacity, u32 chunkBytes)
 {
     const u32 c = blockIdx.x, tid = threadIdx.x;
     const ChunkMeta m = meta[c];
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const u8* __restrict__ src,
         copy_bytes(d + seqAt, slot + seqAt, head + m.bodySize - seqAt, tid, 256);
     } else {
         if (tid < m.fhSize + 3) d[tid] = slot[tid];
-        copy_bytes(d + m.fhSize + 3, src + ((u64)c << kChunkLog), m.srcSize, tid, 256);
+        copy_bytes(d + m.fhSize + 3, src + (u64)c * chunkBytes, m.srcSize, tid, 256);
     }
     if (tail && tid < 4) d[m.outSize - 4 + tid] = (u8)(m.checksum >> (8 * tid));
 }
@@ -77,13 +77,13 @@ __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (6
 __device__ __forceinline__ u64 xxh_round(u64 acc, u64 in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
 __device__ __forceinline__ u64 xxh_merge(u64 acc, u64 v) { acc ^= xxh_round(0, v); return acc * P1 + P4; }
 
-__global__ __launch_bounds__(256) void xxh64_kernel(const u8* __restrict__ src, u64 srcSize, ChunkMeta* __restrict__ meta, u32 nChunks)
+__global__ __launch_bounds__(256) void xxh64_kernel(const u8* __restrict__ src, u64 srcSize, ChunkMeta* __restrict__ meta, u32 nChunks, u32 chunkBytes)
 {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
     const u32 c = t >> 2, j = t & 3;
     if (c >= nChunks) return;           // whole groups of 4 lanes leave together
-    const u64 base = (u64)c << kChunkLog;
-    const u32 n = (u32)((srcSize - base) < kChunkSize ? (srcSize - base) : kChunkSize);
+    const u64 base = (u64)c * chunkBytes;
+    const u32 n = (u32)((srcSize - base) < chunkBytes ? (srcSize - base) : chunkBytes);
     const u8* p = src + base;
     u64 h;
     const u32 stripes = n >> 5;
@@ -110,13 +110,13 @@ void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* to
     hipLaunchKernelGGL(scan_sizes_kernel, dim3(1), dim3(1024), 0, stream, meta, nChunks, offsets, total);
 }
 void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
-                   u32 nChunks, hipStream_t stream)
+                   u32 nChunks, u32 chunkBytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(gather_kernel, dim3(nChunks), dim3(256), 0, stream, src, srcSize, slots, meta, offsets, dst, dstCapacity);
+    hipLaunchKernelGGL(gather_kernel, dim3(nChunks), dim3(256), 0, stream, src, srcSize, slots, meta, offsets, dst, dstCapacity, chunkBytes);
 }
-void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, hipStream_t stream)
+void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(xxh64_kernel, dim3((nChunks * 4 + 255) / 256), dim3(256), 0, stream, src, srcSize, meta, nChunks);
+    hipLaunchKernelGGL(xxh64_kernel, dim3((nChunks * 4 + 255) / 256), dim3(256), 0, stream, src, srcSize, meta, nChunks, chunkBytes);
 }
 
 } // namespace zmi

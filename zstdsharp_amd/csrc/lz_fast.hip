@@ -156,13 +156,21 @@ __device__ __forceinline__ u32 next_match(const LzLds& L, u32 c, u32 par)
 template <int MODE, int SHORT>
 __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
-                                                  ChunkMeta* __restrict__ meta)
+                                                  ChunkMeta* __restrict__ meta,
+                                                  const u8* __restrict__ prefix, const u32 prefixLen, const u32 chunkBytes)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const u64 base = (u64)c << kChunkLog;
-    const u32 n = (u32)((srcSize - base) < kChunkSize ? (srcSize - base) : kChunkSize);
+    // Raw-content dictionary (row f-4; ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5126-5237): its last `prefixLen` bytes
+    // sit in front of the chunk in LDS, ending at a tile boundary (hist = whole tiles of history, positions below lowLimit
+    // are padding and never referenced).  History tiles run the probe/insert half of the loop only; the parse starts
+    // with the cursor at `hist`, so everything after it is untouched: offsets simply reach back into the history.
+    // chunkBytes = 64 KiB - hist (64 KiB without a dictionary).
+    const u32 hist = kChunkSize - chunkBytes, lowLimit = hist - prefixLen;
+    const u64 base = (u64)c * chunkBytes;
+    const u32 nData = (u32)((srcSize - base) < chunkBytes ? (srcSize - base) : chunkBytes);
+    const u32 n = hist + nData;                            // end of the data in LDS
     const u8* __restrict__ in = src + base;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
@@ -171,13 +179,14 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // ---- stage the chunk: 16 B per lane when the source is 16-byte aligned ----
     if ((((uintptr_t)in) & 15) == 0) {
         const uint4* in4 = reinterpret_cast<const uint4*>(in);
-        uint4* l4 = reinterpret_cast<uint4*>(L.in);
-        const u32 full = n >> 4;
+        uint4* l4 = reinterpret_cast<uint4*>(L.in + hist);
+        const u32 full = nData >> 4;
         for (u32 i = tid; i < full; i += kTile) l4[i] = in4[i];
-        for (u32 i = (full << 4) + tid; i < n; i += kTile) L.in[i] = in[i];
+        for (u32 i = (full << 4) + tid; i < nData; i += kTile) L.in[hist + i] = in[i];
     } else {
-        for (u32 i = tid; i < n; i += kTile) L.in[i] = in[i];
+        for (u32 i = tid; i < nData; i += kTile) L.in[hist + i] = in[i];
     }
+    for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     u32* const endOf = reinterpret_cast<u32*>(L.jumpB);
     u32* const table = L.tabMem;                           // fast
@@ -197,7 +206,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
     u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
     // parse state, kept identically in every thread's registers (all updates come from LDS values read after a barrier)
-    u32 cursor = 0;      // absolute position where the parse of the previous tiles ended (= end of the last selected match)
+    u32 cursor = hist;   // absolute position where the parse of the previous tiles ended (= end of the last selected match)
     u32 nbSeq = 0, litBase = 0;
 
     // one selected match -> its sequence + its coverage bits (used by the dense and the sparse path)
@@ -208,7 +217,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 litStart = endOf[rank];
         const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
         // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
-        while (p > floorPos && p > off && L.in[p - 1] == L.in[p - off - 1]) --p;
+        while (p > floorPos && p > off + lowLimit && L.in[p - 1] == L.in[p - off - 1]) --p;
         Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(p - litStart); sq.mlBase = (u16)(end - p - 3);
         seqOut[nbSeq + rank] = sq;
         const u32 r0 = p - tileStart, r1 = (end - tileStart) < kTilePos ? (end - tileStart) : kTilePos;
@@ -245,6 +254,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
+        const bool histTile = tileStart < hist;                                         // uniform: dictionary bytes, insert only
         const u32 nPass = kPPT >> strideLog, par = t % 3;
         covPar = t & 1;
         // (A sparse tile could fuse probe and verify and defer its table inserts behind the verify barrier — one barrier
@@ -265,7 +275,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = probed(j), p = tileStart + q;
-            valid[j] = j < nPass && p + 8 <= n; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
+            valid[j] = j < nPass && p + 8 <= n && p >= lowLimit; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
             if (j >= nPass) continue;            // uniform
             if (valid[j]) {
                 w[j] = lds_load8(L.in, p);
@@ -305,7 +315,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     const u32 lo = (u32)w[j], hi = (u32)(w[j] >> 32);
                     const bool i4 = lo == hi;
                     const bool i3 = __builtin_amdgcn_alignbyte(hi, lo, 3) == lo && ((hi ^ (hi >> 24)) & 0xFFu) == 0;
-                    if ((i4 | i3) && p >= 4) {                     // rare outside runs: only then look at the bytes before p
+                    if ((i4 | i3) && p >= lowLimit + 4) {                     // rare outside runs: only then look at the bytes before p
                         const u32 prev4 = lds_load4(L.in, p - 4);
                         const bool i2 = i4 && ((lo ^ (lo >> 16)) & 0xFFFFu) == 0, i1 = i2 && ((lo ^ (lo >> 8)) & 0xFFu) == 0;
                         if (i4 && prev4 == lo) per = 4;
@@ -368,6 +378,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     }
                 }
             }
+            if (histTile) len = 0;               // history is searched, never parsed
             if (MODE != 0 && SHORT == 4) {
                 // a 4-byte match far away costs more than its literals (offset bits + three codes against ~5 bits a byte)
                 if (len == 4 && off >= 256) len = 0;
@@ -416,7 +427,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) if (valid[j]) atomicMax(&table[hidx(h[j])], ((tileStart + probed(j) + 1) << 16) | htag(h[j]));
         }
-        prevDensity = matchCount << strideLog;
+        prevDensity = histTile ? 0xFFFFFFFFu : matchCount << strideLog;     // history and the tile after it: every position
         const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
         const bool dense = any && matchCount > 64;
         if (dense) {
@@ -601,7 +612,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #endif
     if (tid == 0) {
         ChunkMeta m = {};
-        m.srcSize = n; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(n);
+        m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(nData);
         meta[c] = m;
     }
 }
@@ -617,7 +628,8 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 #endif
 
 template <int MODE, int SHORT>
-static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
+static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
+                       u32 chunkBytes, hipStream_t stream)
 {
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
@@ -626,17 +638,20 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
 // minMatch at levels 4+, was measured and lost ratio on every corpus tried: far 4-byte matches cost more than literals.)
-void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream)
+// prefix/prefixLen: the dictionary bytes every chunk sees as history (null/0 without one); chunkBytes = 64 KiB minus prefixLen
+// rounded up to whole 4 KiB tiles.
+void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
+               u32 chunkBytes, hipStream_t stream)
 {
     switch (finder) {
-    case 0:  launch_one<0, 5>(src, srcSize, nChunks, seqs, lits, meta, stream); break;
-    case 1:  launch_one<1, 5>(src, srcSize, nChunks, seqs, lits, meta, stream); break;
-    default: launch_one<2, 5>(src, srcSize, nChunks, seqs, lits, meta, stream); break;
+    case 0:  launch_one<0, 5>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
+    case 1:  launch_one<1, 5>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
+    default: launch_one<2, 5>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
     }
 }
 

@@ -15,15 +15,16 @@
 
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
-void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, hipStream_t stream);
+void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
+               u32 chunkBytes, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream);
 void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
 void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
-                   u32 nChunks, hipStream_t stream);
-void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, hipStream_t stream);
+                   u32 nChunks, u32 chunkBytes, hipStream_t stream);
+void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, hipStream_t stream);
 // decoder
 size_t decode_walk_workspace_bytes(u64 srcSize);
 void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total [4]=usable*/,
@@ -32,7 +33,7 @@ void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
                             u8* slowFlags, u32 mode, hipStream_t stream);
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, u32* frameActual, hipStream_t stream);
+                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, hipStream_t stream);
 }
 
 using namespace zmi;
@@ -77,6 +78,12 @@ bool is_device_ptr(const void* p)
     return a.type == hipMemoryTypeDevice || a.type == hipMemoryTypeManaged;
 }
 
+// a zstd-format dictionary starts with the magic 0xEC30A437 (ZSTD_MAGIC_DICTIONARY); anything else is raw content
+bool is_formatted_dictionary(const u8* p, size_t n)
+{
+    return n >= 8 && ((u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24)) == 0xEC30A437u;
+}
+
 int device_count()
 {
     int n = 0;
@@ -100,7 +107,22 @@ struct ZSTD_CCtx_s {
     std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
     StageTimer timer;
     float stageMs[kMaxStages] = {}; const char* stageNames[kMaxStages] = {}; int nStages = 0;
+    // raw-content dictionary (ZSTD_CCtx_loadDictionary): the last kDictKeep bytes, host copy + device copy made at the next compression
+    std::vector<u8> dictHost; DevBuf dict; bool dictDirty = false;
 };
+// History per chunk lives in LDS beside the chunk: up to 32 KiB of dictionary in front of 32 KiB chunks, or up to 60 KiB when
+// the whole input fits behind it in one chunk (small records, the usual dictionary case).
+constexpr size_t kDictKeep = 60u << 10;
+static u32 round_tile(size_t n) { return (u32)((n + 4095) & ~(size_t)4095); }
+// -> bytes of dictionary used as history for an input of srcSize bytes (0 = none)
+static u32 dict_prefix_len(const ZSTD_CCtx* c, size_t srcSize)
+{
+    const size_t have = c->dictHost.size();
+    if (have < 8) return 0;                                  // ZSTD_compress_insertDictionary ignores dictionaries < 8 bytes, U/ZstdCompress.cs:5469-5477
+    const size_t wide = have < kDictKeep ? have : kDictKeep;
+    if (srcSize <= kChunkSize - round_tile(wide)) return (u32)wide;
+    return (u32)(have < (32u << 10) ? have : (32u << 10));
+}
 
 struct ZSTD_DCtx_s {
     int windowLogMax = 27;
@@ -110,7 +132,9 @@ struct ZSTD_DCtx_s {
     StageTimer timer;
     // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
     std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
-    u32 litDecoder = 0;         // 0 auto, 1 serial (4 lanes per frame), 2 self-synchronising (256 lanes per frame)
+    u32 litDecoder = 0;         // 0 auto, 1 serial (4 lanes per frame), 2 self-synchronising (256 lanes per frame), 3 serial with compact tables
+    // raw-content dictionary (ZSTD_DCtx_loadDictionary): host copy, uploaded at the next decompression
+    std::vector<u8> dictHost; DevBuf dict; bool dictDirty = false;
 };
 
 
@@ -169,7 +193,18 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         (void)hipStreamSynchronize(s);
         return n;
     }
-    const u64 totalChunks = (srcSize + kChunkSize - 1) / kChunkSize;
+    const u32 prefixLen = dict_prefix_len(c, srcSize);
+    const u32 chunkBytes = kChunkSize - round_tile(prefixLen);
+    if (c->dictDirty) {
+        if (!c->dictHost.empty()) {
+            if (!c->dict.ensure(c->dictHost.size() + 64)) return ZERR(kErrMemoryAllocation);
+            if (hipMemcpyAsync(c->dict.p, c->dictHost.data(), c->dictHost.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+            if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        }
+        c->dictDirty = false;
+    }
+    const u8* prefix = prefixLen ? (const u8*)c->dict.p + (c->dictHost.size() - prefixLen) : nullptr;
+    const u64 totalChunks = (srcSize + chunkBytes - 1) / chunkBytes;
     const u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = strategy_for_level(c->level);
@@ -177,20 +212,20 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
     bool first = true;
     for (u64 c0 = 0; c0 < totalChunks; c0 += passChunks) {
         const u32 nChunks = (u32)((totalChunks - c0) < passChunks ? (totalChunks - c0) : passChunks);
-        const u8* src = d_src + c0 * kChunkSize;
-        const u64 n = (srcSize - c0 * kChunkSize) < (u64)nChunks * kChunkSize ? (srcSize - c0 * kChunkSize) : (u64)nChunks * kChunkSize;
+        const u8* src = d_src + c0 * chunkBytes;
+        const u64 n = (srcSize - c0 * chunkBytes) < (u64)nChunks * chunkBytes ? (srcSize - c0 * chunkBytes) : (u64)nChunks * chunkBytes;
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         if (first) c->timer.begin(s);
-        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, s);                      if (first) c->timer.mark("lz_fast", s);
+        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, s);                      if (first) c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, s);                        if (first) c->timer.mark("huf_build", s);
-        if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, s);             if (first) c->timer.mark("xxh64", s); }
+        if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             if (first) c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, s);   if (first) c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       if (first) c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
         launch_huf_encode(lits, meta, tables, slots, d_dst + produced, offsets, room, nChunks, s);   if (first) c->timer.mark("huf_encode", s);
-        launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, s);      if (first) c->timer.mark("gather", s);
+        launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, chunkBytes, s);      if (first) c->timer.mark("gather", s);
         u64 passTotal = 0;
         if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
         if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
@@ -215,7 +250,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
         (void)hipSetDevice(c->device);
         if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
         c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release();
-        c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release();
+        c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release();
         c->timer.destroy();
         if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     }
@@ -268,11 +303,26 @@ size_t ZSTD_CCtx_getParameter(const ZSTD_CCtx* c, int param, int* value)
     }
 }
 
+// Raw-content dictionaries only (ZSTD_compress_insertDictionary's dct_auto branch without the magic ->
+// ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5465-5503, 5126-5237); the frames carry no dictID (there is none), exactly as
+// the reference writes them.  A formatted dictionary (magic 0xEC30A437) is refused.
 size_t ZSTD_CCtx_loadDictionary(ZSTD_CCtx* c, const void* dict, size_t dictSize)
 {
     if (!c) return ZERR(kErrGeneric);
-    if (dict == nullptr || dictSize == 0) return 0;          /* "no dictionary" */
-    return ZERR(kErrParameterUnsupported);
+    if (!c->sIn.empty() || c->sEnding) return ZERR(kErrStageWrong);        /* not in the middle of a streaming frame session, U/ZstdCompress.cs:1273 */
+    if (dict == nullptr || dictSize == 0) { c->dictHost.clear(); c->dictDirty = true; return 0; }          /* "no dictionary" */
+    const size_t keep = dictSize < kDictKeep ? dictSize : kDictKeep;
+    std::vector<u8> h(dictSize < 8 ? dictSize : keep);
+    const u8* tail = (const u8*)dict + (dictSize - h.size());
+    u8 head[8] = {};
+    if (is_device_ptr(dict)) {
+        if (hipMemcpy(h.data(), tail, h.size(), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipMemcpy(head, dict, dictSize < 8 ? dictSize : 8, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    } else { memcpy(h.data(), tail, h.size()); memcpy(head, dict, dictSize < 8 ? dictSize : 8); }
+    if (is_formatted_dictionary(head, dictSize)) return ZERR(kErrParameterUnsupported);
+    c->dictHost.swap(h);
+    c->dictDirty = true;
+    return 0;
 }
 
 size_t ZSTD_compressBound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
@@ -333,7 +383,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->actual.release();
+        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->actual.release(); d->dict.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -352,11 +402,22 @@ size_t ZSTD_DCtx_getParameter(ZSTD_DCtx* d, int param, int* value)
     if (param == ZSTD_d_windowLogMax) { *value = d->windowLogMax; return 0; }
     return ZERR(kErrParameterUnsupported);
 }
+// Raw-content dictionaries only (ZSTD_decompress_insertDictionary's "no magic" branch -> ZSTD_refDictContent,
+// U/ZstdDecompress.cs:1909-1931, 1758-1771): the bytes become history in front of every frame.  A formatted dictionary
+// (magic 0xEC30A437: entropy tables + repcodes + dictID) is refused, never half-applied.
 size_t ZSTD_DCtx_loadDictionary(ZSTD_DCtx* d, const void* dict, size_t dictSize)
 {
     if (!d) return ZERR(kErrGeneric);
-    if (dict == nullptr || dictSize == 0) return 0;
-    return ZERR(kErrParameterUnsupported);
+    if (dict == nullptr || dictSize == 0) { d->dictHost.clear(); d->dictDirty = true; return 0; }
+    if (dictSize > (size_t)1 << 30) return ZERR(kErrParameterUnsupported);
+    std::vector<u8> h(dictSize);
+    if (is_device_ptr(dict)) {
+        if (hipMemcpy(h.data(), dict, dictSize, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    } else memcpy(h.data(), dict, dictSize);
+    if (is_formatted_dictionary(h.data(), dictSize)) return ZERR(kErrParameterUnsupported);
+    d->dictHost.swap(h);
+    d->dictDirty = true;
+    return 0;
 }
 
 // Host-side header walk for host buffers (ZSTD_findFrameSizeInfo, U/ZstdDecompress.cs:877-951): headers only, no payload.
@@ -482,7 +543,16 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     // slots, report their regenerated size, and are then moved down to close the gaps
     const u32 nUnsized = serialWalk ? st[5] : 0u;
     if (nUnsized && !d->actual.ensure((size_t)nFrames * sizeof(u32))) return ZERR(kErrMemoryAllocation);
-    launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, nUnsized ? (u32*)d->actual.p : nullptr, s);   d->timer.mark("decode_sequences", s);
+    if (d->dictDirty) {
+        if (!d->dictHost.empty()) {
+            if (!d->dict.ensure(d->dictHost.size() + 64)) return ZERR(kErrMemoryAllocation);
+            if (hipMemcpyAsync(d->dict.p, d->dictHost.data(), d->dictHost.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+            if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        }
+        d->dictDirty = false;
+    }
+    launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, nUnsized ? (u32*)d->actual.p : nullptr,
+                            d->dictHost.empty() ? nullptr : (const u8*)d->dict.p, (u32)d->dictHost.size(), s);   d->timer.mark("decode_sequences", s);
     u32 err = 0;
     if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }

@@ -41,6 +41,9 @@ class CompressionStream:
     def SetParameter(self, parameter, value):
         self.compressor.SetParameter(parameter, value)
 
+    def LoadDictionary(self, dict_bytes):                     # S/CompressionStream.cs:58-62
+        self.compressor.LoadDictionary(dict_bytes)
+
     def _write_internal(self, data, last: bool):
         if self._disposed:
             raise ValueError("ObjectDisposedException: CompressionStream")
@@ -98,6 +101,9 @@ class DecompressionStream:
         self._last = 0
         self._leaveOpen = leaveOpen
         self._disposed = False
+
+    def LoadDictionary(self, dict_bytes):                     # S/DecompressionStream.cs:58-62
+        self.decompressor.LoadDictionary(dict_bytes)
 
     def Read(self, count: int) -> bytes:
         if self._disposed:
