@@ -133,3 +133,35 @@ def test_greedy_row_hash_levels_round_trip(oracle):
                     if comp == -40:
                         continue
                     assert isinstance(comp, bytes) and oracle.decompress(comp, n) == data, (kind, n, level, chunk)
+
+
+def test_raw_content_dictionary_frames(oracle):
+    """Row f-4's checker: the oracle's dictionary decoder (ZSTD_refDictContent + ZSTD_execSequence's extDict branch,
+    U/ZstdDecompress.cs:1758-1771, U/ZstdDecompressBlock.cs:2223-2250) against its dictionary-frame generator.
+    Parity unpinned for the frame BYTES (the reference holds no dictionary fixtures); pinned behaviour: a dictionary
+    frame restores the data with the dictionary, fails without it (T/ZstdNetTests.cs:95-113), dictionaries under 8 bytes
+    are ignored (U/ZstdCompress.cs:5469-5477), dictionary-less frames decode with any dictionary loaded (:76-93)."""
+    import numpy as np
+    r = np.random.default_rng(3)
+    vocab = [bytes(r.integers(97, 123, size=int(r.integers(3, 10))).astype(np.uint8)) for _ in range(200)]
+
+    def text(n, seed):
+        g = np.random.default_rng(seed); out = bytearray()
+        while len(out) < n:
+            out += vocab[int(g.integers(0, len(vocab)))] + b" "
+        return bytes(out[:n])
+
+    dic = text(20000, 1)
+    for n in (0, 1, 8, 100, 3000, 70000, 300000):
+        data = text(n, n + 2)
+        for chk in (0, 1):
+            frame = oracle.compress_dict(data, dic, 1, chk)
+            assert not isinstance(frame, int)
+            assert oracle.decompress(frame, n, dic) == data
+            if n >= 100:
+                assert len(frame) < len(oracle.compress(data, 1, chk))          # the dictionary helps (T/ZstdNetTests.cs:148-164)
+                assert oracle.decompress(frame, n) in (-20, -22)                 # corruption_detected / checksum_wrong without it
+        assert oracle.decompress(oracle.compress(data, 1, 0), n, dic) == data
+        assert oracle.compress_dict(data, b"1234567", 1, 0) == oracle.compress(data, 1, 0)
+    assert oracle.compress_dict(b"x" * 100, bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(60), 1, 0) == -40    # formatted: not restated
+    assert oracle.compress_dict(text(5000, 9), dic, 3, 0) == -40                                           # fast strategy only
