@@ -778,23 +778,28 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
 // 2.4 KiB per frame -> 64 frames per CU -> one round.  Same acceptance as the other forms; tableLog 12 goes the slow way.
 // =====================================================================================================================
 struct CompactLds {
-    u16 huf[1024];              // byte | nbBits << 8, or 0xF000 | pair index.  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
-    u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded; entries 2k, 2k+1 = pair k when tableLog = 11
+    u16 huf[1024];              // byte | nbBits << 8 (entries owned by 11-bit codes are unused).  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
+    u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded; its head = the 11-bit codes in table order
     u32 classStart[14];         // first index (in the tableLog-bit table) of weight class w; [tableLog + 1] = table size
     u32 classFirst[14];         // index into sorted[] of the first symbol of class w
     u32 meta[4];
 };
 
-__device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ table, const u8* __restrict__ sorted, u32 tableLog,
+// n1 = number of 11-bit codes when tableLog = 11 (else 0).  In the canonical order (HUF_readDTableX1: weight classes ascending)
+// they own the first n1 entries of the 11-bit table, one each, so "the next 11 bits < n1" identifies them and indexes `sorted`
+// directly: the symbol read and the 10-bit table read are issued together and one select picks — a single LDS latency per
+// symbol whatever the code length, no branch.
+__device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ table, const u8* __restrict__ sorted, u32 tableLog, u32 n1,
                                                     const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
 {
     if (srcSize < 1) return false;
     const u32 idxBits = tableLog > 10 ? 10u : tableLog;
     s32 remaining; u32 i = 0;
     auto lookup = [&](u32 top32) -> u32 {                 // top32 = the next 32 stream bits
-        u32 e = table[top32 >> (32 - idxBits)];
-        if (e >= 0xF000u) e = (u32)sorted[2 * (e & 0xFFFu) + ((top32 >> 21) & 1u)] | (11u << 8);
-        return e;
+        const u32 top = top32 >> (31 - idxBits);          // idxBits + 1 bits
+        const u32 e10 = table[top >> 1];
+        const u32 e1 = sorted[top & 255u];
+        return top < n1 ? (e1 | (11u << 8)) : e10;
     };
     if (srcSize >= 16) {
         s32 ptr = (s32)srcSize - 8;
@@ -852,7 +857,7 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
 {
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
     u32 ip = h.headerSize, litOff = 0;
-    bool haveTable = false; u32 tableLog = 0;
+    bool haveTable = false; u32 tableLog = 0, n1 = 0;
     for (;;) {
         if (fd.srcSize - ip < 3) return kErrSrcSizeWrong;
         const u32 bh = readLE24(fsrc + ip);
@@ -907,7 +912,7 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                                 for (u32 cw = 2; cw <= tableLog; ++cw) if (Q.classFirst[cw] <= k) w = cw;
                                 const u32 start = Q.classStart[w] + ((k - Q.classFirst[w]) << (w - 1));     // index in the tableLog-bit table
                                 const u32 sym = Q.sorted[k];
-                                if (drop && w == 1) { if (!(start & 1)) Q.huf[start >> 1] = (u16)(0xF000u | (start >> 1)); continue; }
+                                if (drop && w == 1) continue;           // 11-bit codes are read from `sorted` (see huf_decode_stream4c)
                                 const u32 len = ((1u << w) >> 1) >> drop, st = start >> drop;
                                 const u32 e = sym | ((tableLog + 1 - w) << 8);
                                 if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
@@ -916,12 +921,13 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                         haveTable = true;
+                        n1 = tableLog > 10 ? Q.classFirst[2] : 0u;
                         hsrc += hs; hlen -= hs;
                     } else if (!haveTable) return kErrDictionaryCorrupted;
                     u8* const dst = litOut + litOff;
                     bool ok = true;
                     if (lh.single) {
-                        if (ql == 0) ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, hsrc, hlen, dst, lh.litSize);
+                        if (ql == 0) ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, n1, hsrc, hlen, dst, lh.litSize);
                     } else {
                         if (hlen < 10) return kErrCorruption;
                         const u32 l1 = readLE16(hsrc), l2 = readLE16(hsrc + 2), l3 = readLE16(hsrc + 4);
@@ -932,7 +938,7 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                         const u32 so = ql == 0 ? 6 : ql == 1 ? 6 + l1 : ql == 2 ? 6 + l1 + l2 : 6 + l1 + l2 + l3;
                         const u32 sl = ql == 0 ? l1 : ql == 1 ? l2 : ql == 2 ? l3 : l4;
                         const u32 on = ql < 3 ? seg : lh.litSize - 3 * seg;
-                        ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, hsrc + so, sl, dst + ql * seg, on);
+                        ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, n1, hsrc + so, sl, dst + ql * seg, on);
                     }
                     if (ql == 0) Q.meta[3] = 0;
                     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
