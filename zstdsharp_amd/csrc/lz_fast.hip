@@ -211,21 +211,24 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 
     // one selected match -> its sequence + its coverage bits (used by the dense and the sparse path)
     u32 covPar = 0;                      // coverage-mask slot of the current tile
-    auto emit_match = [&](u32 tileStart, u32 q, u32 rank, u32 end) {
+    u64* cov = L.covMask[0];             // coverage words of the current tile (64, or 256 for a super-tile)
+    u32 span = kTilePos;                 // positions the current tile covers
+    // ix = index into the tile arrays (the position, or the probe slot of a super-tile), q = tile-relative position
+    auto emit_match = [&](u32 tileStart, u32 ix, u32 q, u32 rank, u32 end) {
         u32 p = tileStart + q;
-        const u32 off = L.tileOff[q];
+        const u32 off = L.tileOff[ix];
         const u32 litStart = endOf[rank];
         const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
         // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
         while (p > floorPos && p > off + lowLimit && L.in[p - 1] == L.in[p - off - 1]) --p;
         Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(p - litStart); sq.mlBase = (u16)(end - p - 3);
         seqOut[nbSeq + rank] = sq;
-        const u32 r0 = p - tileStart, r1 = (end - tileStart) < kTilePos ? (end - tileStart) : kTilePos;
+        const u32 r0 = p - tileStart, r1 = (end - tileStart) < span ? (end - tileStart) : span;
         for (u32 wI = r0 >> 6; wI <= ((r1 - 1) >> 6); ++wI) {
             u64 m = ~0ull;
             if (wI == (r0 >> 6)) m &= ~0ull << (r0 & 63);
             if (wI == ((r1 - 1) >> 6)) m &= ~0ull >> (63 - ((r1 - 1) & 63));
-            atomicOr((unsigned long long*)&L.covMask[covPar][wI], (unsigned long long)m);
+            atomicOr((unsigned long long*)&cov[wI], (unsigned long long)m);
         }
     };
     // full length of a match that hit the cap: 64 lanes x 8 bytes per step (whole wave, uniform arguments)
@@ -250,13 +253,27 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // acceleration (ZSTD_fast's step = 1 + ((ip - anchor) >> kSearchStrength), U/ZstdFast.cs:130-136).  A match that starts
     // between probed positions is still picked up one or two bytes later and grown backward at emission.
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
-    for (u32 t = 0; t < nTiles; ++t) {
+    u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
+    for (u32 t = 0, it = 0; t < nTiles; ++it) {
         const u32 tileStart = t * kTilePos;
-        const u32 stamp = ((kChunkSize / kTilePos - 1) - t) << kTileLog;
         const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
         const bool histTile = tileStart < hist;                                         // uniform: dictionary bytes, insert only
-        const u32 nPass = kPPT >> strideLog, par = t % 3;
-        covPar = t & 1;
+        // Super-tile: where only every 2nd / 4th position is probed, TWO / FOUR tiles (as many as are left in full) are taken
+        // in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies overlap and the
+        // two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot (slot order = position
+        // order), coverage has up to 256 words, and the selection is the serial walk of wave 0 whatever the number of
+        // matches (capped; what is left out stays literals).
+        u32 nSubT = 1u << strideLog;
+        { const u32 fullLeft = (n - tileStart) >> kTileLog; if (nSubT > fullLeft) nSubT = fullLeft; }
+        const bool super = nSubT >= 2 && !histTile;                                     // uniform
+        if (!super) nSubT = 1;
+        span = nSubT << kTileLog;
+        // first-occurrence entries: base + tile-relative position, 16 bits, smaller for later tiles (atomicMin keeps the
+        // current tile's earliest).  Tile t owns [(15-t) << 12, +4096); a super-tile owns the ranges of the tiles it covers.
+        const u32 stamp = ((kChunkSize / kTilePos) - t - nSubT) << kTileLog;
+        const u32 nPass = (kPPT >> strideLog) * nSubT, par = it % 3;
+        covPar = it & 1;
+        cov = super ? superCov : L.covMask[covPar];
         // (A sparse tile could fuse probe and verify and defer its table inserts behind the verify barrier — one barrier
         // less, measured 7 % faster — but the next tile's probes would then race with those inserts and the output would
         // depend on wave timing.  Determinism is part of the contract, so the two-barrier form stays.)
@@ -264,11 +281,13 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // probed position of lattice cell c = j * kTile + tid: c * stride + a pseudo-random residue, so that a repeat of
         // earlier data lines up with inserted positions one time in `stride` whatever its distance (a fixed lattice would
         // never see a repeat whose distance is not a multiple of the stride)
-        auto probed = [&](u32 j) -> u32 {
-            const u32 cI = j * kTile + tid;
+        auto slot_pos = [&](u32 cI) -> u32 {
             if (strideLog == 0) return cI;                   // (uniform) dense tile: every position
             return (cI << strideLog) + ((((tileStart >> kTileLog) * kTilePos + cI) * 2654435761u >> 27) & ((1u << strideLog) - 1));
         };
+        auto probed = [&](u32 j) -> u32 { return slot_pos(j * kTile + tid); };
+        // index into tileLen/tileOff/the match masks: the position, or the probe slot in a super-tile
+        auto arr_ix = [&](u32 j, u32 q) -> u32 { return super ? j * kTile + tid : q; };
         // ---------------- probe ----------------
         // fast: h = hash product, cand = table entry.  dual: h = long product, h2 = short product, cand = tableL | tableS << 16
         u64 w[kPPT]; u32 h[kPPT], h2[kPPT], cand[kPPT]; bool valid[kPPT];
@@ -282,12 +301,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 if (MODE == 0) {
                     h[j] = hash6p(w[j]);
                     cand[j] = table[hidx(h[j])];
-                    if (!fused) atomicMin(&first[hidx(h[j])], ((stamp | q) << 16) | htag(h[j]));
+                    if (!fused) atomicMin(&first[hidx(h[j])], ((stamp + q) << 16) | htag(h[j]));
                 } else {
                     h[j] = hash8p(w[j]); h2[j] = hash_shortp<SHORT>(w[j]);
                     const u32 hL = hidx(h[j]), hS = hidx(h2[j]);
                     cand[j] = (u32)tableL[hL] | ((u32)tableS[hS] << 16);
-                    atomicMin(&firstL[hL >> 1], ((stamp | q) << 16) | htag(h[j])); atomicMin(&firstS[hS >> 1], ((stamp | q) << 16) | htag(h2[j]));
+                    atomicMin(&firstL[hL >> 1], ((stamp + q) << 16) | htag(h[j])); atomicMin(&firstS[hS >> 1], ((stamp + q) << 16) | htag(h2[j]));
                 }
             }
         }
@@ -295,10 +314,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         if (!fused) __syncthreads();           // every probe of this tile precedes every insert of this tile
         ZMI_STAMP(2);
         u64 mmJ[kPPT], cmJ[kPPT];
-        if (strideLog != 0 && lane < 4) {        // strided tile: a wave's probes fall into its own four groups; matching lanes set bits below
+        const bool slotMasks = strideLog == 0 || super;      // (uniform) array index = j * kTile + tid: a wave's ballots ARE its mask words
+        if (!slotMasks && lane < 4) {            // strided tile: a wave's probes fall into its own four groups; matching lanes set bits below
             const u32 g = strideLog == 2 ? wave * 4 + lane : (lane >> 1) * 32 + wave * 2 + (lane & 1);
             L.matchMask[g] = 0; L.capMask[g] = 0; L.selMask[g] = 0; L.covMask[covPar][g] = 0;
         }
+        if (super && tid < nSubT * kGroups) superCov[tid] = 0;
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             mmJ[j] = 0; cmJ[j] = 0;
@@ -330,7 +351,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                         // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
                         const u32 tag = htag(h[j]);
                         const u32 f = fused ? 0xFFFFFFFFu : first[hidx(h[j])];
-                        const u32 fq = (f >> 16) & (kTilePos - 1);
+                        const u32 fq = (f >> 16) - stamp;                 // (an entry seen here was written by this tile: see `stamp`)
                         if (!fused && fq < q && (f & 0xFFFFu) == tag) {
                             const u32 cpos = tileStart + fq;
                             len = match_len(L, p, cpos, w[j], n); off = p - cpos;
@@ -347,13 +368,13 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     const u32 fL = eL >> 16, fS = eS >> 16;
                     // the first position of a bucket in this tile becomes the bucket's entry for later tiles: one writer per
                     // entry, no atomic (two positions with the same 13-bit hash share the 12-bit bucket)
-                    if (fL == (stamp | q)) tableL[hL] = (u16)(p + 1);
-                    if (fS == (stamp | q)) tableS[hS] = (u16)(p + 1);
+                    if (fL == stamp + q) tableL[hL] = (u16)(p + 1);
+                    if (fS == stamp + q) tableS[hS] = (u16)(p + 1);
                     if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
                     // candidates, longest wins, nearer on ties: in-tile long, earlier-tile long, in-tile short, earlier-tile short
                     u32 c0p = 0xFFFFFFFFu, c1p = 0xFFFFFFFFu;
-                    if (len < kLenCap && (fL & (kTilePos - 1)) < q && (eL & 0xFFFFu) == htag(h[j])) {
-                        c0p = tileStart + (fL & (kTilePos - 1));
+                    if (len < kLenCap && fL - stamp < q && (eL & 0xFFFFu) == htag(h[j])) {
+                        c0p = tileStart + (fL - stamp);
                         const u32 l2 = match_len(L, p, c0p, w[j], n);
                         if (l2 > len || (l2 == len && l2 && p - c0p < off)) { len = l2; off = p - c0p; }
                     }
@@ -362,8 +383,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                         const u32 l2 = match_len(L, p, c1p, w[j], n);
                         if (l2 > len) { len = l2; off = p - c1p; }
                     }
-                    if (len < kLenCap && (fS & (kTilePos - 1)) < q && (eS & 0xFFFFu) == htag(h2[j])) {
-                        const u32 cp = tileStart + (fS & (kTilePos - 1));
+                    if (len < kLenCap && fS - stamp < q && (eS & 0xFFFFu) == htag(h2[j])) {
+                        const u32 cp = tileStart + (fS - stamp);
                         if (cp != c0p) {
                             const u32 l2 = match_len(L, p, cp, w[j], n);
                             if (l2 > len || (l2 == len && l2 && p - cp < off)) { len = l2; off = p - cp; }
@@ -394,9 +415,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (g2 > g1) len = 0;
                 }
             }
-            if (len) { L.tileLen[q] = (u8)len; L.tileOff[q] = (u16)off; }      // only read where matchMask has the bit
+            if (len) { const u32 ix = arr_ix(j, q); L.tileLen[ix] = (u8)len; L.tileOff[ix] = (u16)off; }      // only read where matchMask has the bit
             mmJ[j] = ballot(len != 0); cmJ[j] = ballot(len == kLenCap);
-            if (strideLog != 0) {
+            if (!slotMasks) {
                 if (len) {
                     atomicOr((unsigned long long*)&L.matchMask[q >> 6], 1ull << (q & 63));
                     if (len == kLenCap) atomicOr((unsigned long long*)&L.capMask[q >> 6], 1ull << (q & 63));
@@ -405,7 +426,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 if (lane == 0 && mmJ[j]) atomicAdd(&L.matchCount[par], popc64(mmJ[j]));
             }
         }
-        if (strideLog == 0) {   // the wave's four groups of masks are written together by lanes 0..3 (one predicated block instead of four)
+        if (slotMasks) {        // the wave's four groups of masks are written together by lanes 0..3 (one predicated block instead of four)
             u64 mmL = mmJ[0], cmL = cmJ[0];
 #pragma unroll
             for (u32 k = 1; k < kPPT; ++k) { mmL = lane == k ? mmJ[k] : mmL; cmL = lane == k ? cmJ[k] : cmL; }
@@ -422,14 +443,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
         const u32 matchCount = L.matchCount[par];
-        if (tid == 0) { const u32 nx = (t + 2) % 3; L.nzWords[nx] = 0; L.matchCount[nx] = 0; }     // slot of tile t + 2: idle until the next barrier
+        if (tid == 0) { const u32 nx = (it + 2) % 3; L.nzWords[nx] = 0; L.matchCount[nx] = 0; }    // slot of the iteration after next: idle until the next barrier
         if (fused) {                           // the deferred inserts of a sparse tile (every probe of the tile came before the barrier)
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) if (valid[j]) atomicMax(&table[hidx(h[j])], ((tileStart + probed(j) + 1) << 16) | htag(h[j]));
         }
-        prevDensity = histTile ? 0xFFFFFFFFu : matchCount << strideLog;     // history and the tile after it: every position
-        const bool any = matchCount != 0 && c0 < kTilePos;               // uniform
-        const bool dense = any && matchCount > 64;
+        // matches per 4096 positions had every position been probed
+        prevDensity = histTile ? 0xFFFFFFFFu : (matchCount << strideLog) / nSubT;     // history and the tile after it: every position
+        const bool any = matchCount != 0 && c0 < span;                   // uniform
+        const bool dense = any && matchCount > 64 && !super;
         if (dense) {
             // ---------------- select: orbit of the greedy parse by pointer doubling ----------------
             u16* cur = L.jump; u16* nxt = L.jumpB;
@@ -533,38 +555,50 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
             __syncthreads();
 #pragma unroll
-            for (u32 j = 0; j < kPPT; ++j) if (sel[j]) emit_match(tileStart, j * kTile + tid, myRank[j], myEnd[j]);
+            for (u32 j = 0; j < kPPT; ++j) if (sel[j]) emit_match(tileStart, j * kTile + tid, j * kTile + tid, myRank[j], myEnd[j]);
         } else if (any) {
-            // ---------------- sparse tile (<= 64 matches): wave 0 parses it alone, exactly greedy ----------------
+            // ---------------- sparse tile (<= 64 matches) or super-tile: wave 0 parses it alone, exactly greedy ----------------
+            // (a super-tile may hold more than 64 matches: they are walked 64 at a time, at most kSuperMax of them — the
+            //  rest stays literals; it happens where sparse data turns dense, and the next tile is a dense one)
             if (wave == 0) {
-                {   // the tile's matches in position order -> one per lane
-                    const u64 mmw = L.matchMask[lane];
-                    const u32 cnt = popc64(mmw);
-                    u32 r = wave_scan_incl(cnt) - cnt;
-                    for (u64 b = mmw; b; b &= b - 1) L.sparseList[r++] = (u16)(lane * 64 + ctz64(b));
+                constexpr u32 kSuperMax = 1024;
+                const u32 mcount = matchCount < kSuperMax ? matchCount : kSuperMax;
+                const u64 mmw = L.matchMask[lane];                     // lane = group of 64 array slots
+                const u32 cntW = popc64(mmw);
+                const u32 rankW = wave_scan_incl(cntW) - cntW;          // matches before this lane's group
+                u32 cur = c0, nSelTot = 0;
+                if (lane == 0) endOf[0] = cursor;
+                for (u32 b0 = 0; b0 < mcount; b0 += 64) {
+                    {   // matches of rank [b0, b0 + 64) in position order -> one per lane
+                        u32 r = rankW;
+                        for (u64 b = mmw; b; b &= b - 1, ++r) if (r - b0 < 64u) L.sparseList[r - b0] = (u16)(lane * 64 + ctz64(b));
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    const u32 nB = mcount - b0 < 64u ? mcount - b0 : 64u;
+                    const bool have = lane < nB;
+                    const u32 ix = have ? L.sparseList[lane] : 0;
+                    const u32 q = super ? slot_pos(ix) : ix;
+                    const u32 len = have ? L.tileLen[ix] : 0, off = have ? L.tileOff[ix] : 0;
+                    u32 myEnd = 0; u64 selBits = 0;
+                    for (u32 i = 0; i < nB; ++i) {
+                        const u32 qi = read_lane(q, i);
+                        if (qi < cur) continue;
+                        const u32 li = read_lane(len, i);
+                        u32 e = tileStart + qi + li;
+                        if (li == kLenCap) e = finish_capped(tileStart + qi, read_lane(off, i));
+                        if (lane == i) myEnd = e;
+                        selBits |= 1ull << i;
+                        cur = e - tileStart;
+                    }
+                    const bool sel = (selBits >> lane) & 1ull;
+                    const u32 rank = nSelTot + popc64(selBits & lanemask_lt());
+                    if (sel) endOf[rank + 1] = myEnd;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+                    if (sel) emit_match(tileStart, ix, q, rank, myEnd);
+                    nSelTot += popc64(selBits);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                const bool have = lane < matchCount;
-                const u32 q = have ? L.sparseList[lane] : 0;
-                const u32 len = have ? L.tileLen[q] : 0, off = have ? L.tileOff[q] : 0;
-                u32 myEnd = 0; u64 selBits = 0; u32 cur = c0;
-                for (u32 i = 0; i < matchCount; ++i) {
-                    const u32 qi = read_lane(q, i);
-                    if (qi < cur) continue;
-                    const u32 li = read_lane(len, i);
-                    u32 e = tileStart + qi + li;
-                    if (li == kLenCap) e = finish_capped(tileStart + qi, read_lane(off, i));
-                    if (lane == i) myEnd = e;
-                    selBits |= 1ull << i;
-                    cur = e - tileStart;
-                }
-                const bool sel = (selBits >> lane) & 1ull;
-                const u32 rank = popc64(selBits & lanemask_lt());
-                const u32 nSel = popc64(selBits);
-                if (lane == 0) { endOf[0] = cursor; L.wordRank[64] = nSel; }
-                if (sel) endOf[rank + 1] = myEnd;
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-                if (sel) emit_match(tileStart, q, rank, myEnd);
+                if (lane == 0) L.wordRank[64] = nSelTot;
             }
         }
         ZMI_STAMP(5);
@@ -572,39 +606,49 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(6);
         const u32 nSel = any ? L.wordRank[64] : 0u;
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
-        if (!any && c0 == 0 && tileStart + kTilePos <= n) {
+        const u32 nSub = span >> kTileLog;          // 1, or 4 in a super-tile: the compaction below runs per 4096 positions
+        if (!any && c0 == 0 && tileStart + span <= n) {
             // nothing selected, nothing carried in, full tile: every byte is a literal, copied straight through
-            const u32 q4 = tid * 4;
-            *(u32u*)(litOut + litBase + q4) = *reinterpret_cast<const u32*>(L.in + tileStart + q4);
-            litBase += kTilePos;
-        } else {
-            // Every wave scans the 64 group words itself (one LDS read per lane), so the compaction offsets need neither a
-            // cross-wave table nor another barrier.  keepG(g) = bytes of group g that are literals of this tile.
-            auto keepG = [&](u32 g) -> u64 {
-                const u32 g0 = g * 64;
-                u64 k = ~L.covMask[covPar][g];
-                const u32 pG = tileStart + g0;
-                if (pG >= n) k = 0; else if (n - pG < 64) k &= (1ull << (n - pG)) - 1;
-                if (c0 > g0) k = (c0 - g0 >= 64) ? 0ull : (k & (~0ull << (c0 - g0)));      // before the entry cursor: inside an earlier match
-                return k;
-            };
-            const u32 gcnt = popc64(keepG(lane));
-            const u32 gincl = wave_scan_incl(gcnt);
-            const u32 total = read_lane(gincl, 63);
-            const u32 q4 = tid * 4, myG = q4 >> 6;           // 1024 threads cover the tile, 4 positions each
-            const u32 p = tileStart + q4;
-            const u64 kg = keepG(myG);
-            const u32 gexcl = __shfl(gincl - gcnt, (int)myG);
-            const u32 keep = (u32)(kg >> (q4 & 63)) & 0xFu;
-            const u32 lastEnd = nSel ? endOf[nSel] : cursor;
-            if (keep) {
-                u8* o = litOut + litBase + gexcl + popc64(kg & ((1ull << (q4 & 63)) - 1));
-                const u32 v = *reinterpret_cast<const u32*>(L.in + p);
-                if (keep == 0xFu) *(u32u*)o = v;
-                else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
+            for (u32 sub = 0; sub < nSub; ++sub) {
+                const u32 q4 = sub * kTilePos + tid * 4;
+                *(u32u*)(litOut + litBase + q4) = *reinterpret_cast<const u32*>(L.in + tileStart + q4);
             }
-            litBase += total; nbSeq += nSel; cursor = lastEnd;
+            litBase += span;
+        } else {
+            const u32 lastEnd = nSel ? endOf[nSel] : cursor;
+            for (u32 sub = 0; sub < nSub; ++sub) {
+                // Every wave scans the 64 group words itself (one LDS read per lane), so the compaction offsets need neither a
+                // cross-wave table nor another barrier.  keepG(g) = bytes of group g that are literals of this tile.
+                const u64* const cw = cov + sub * kGroups;
+                const u32 subStart = tileStart + sub * kTilePos;
+                const u32 c0s = c0 > sub * kTilePos ? c0 - sub * kTilePos : 0u;
+                auto keepG = [&](u32 g) -> u64 {
+                    const u32 g0 = g * 64;
+                    u64 k = ~cw[g];
+                    const u32 pG = subStart + g0;
+                    if (pG >= n) k = 0; else if (n - pG < 64) k &= (1ull << (n - pG)) - 1;
+                    if (c0s > g0) k = (c0s - g0 >= 64) ? 0ull : (k & (~0ull << (c0s - g0)));      // before the entry cursor: inside an earlier match
+                    return k;
+                };
+                const u32 gcnt = popc64(keepG(lane));
+                const u32 gincl = wave_scan_incl(gcnt);
+                const u32 total = read_lane(gincl, 63);
+                const u32 q4 = tid * 4, myG = q4 >> 6;           // 1024 threads cover 4096 positions, 4 each
+                const u32 p = subStart + q4;
+                const u64 kg = keepG(myG);
+                const u32 gexcl = __shfl(gincl - gcnt, (int)myG);
+                const u32 keep = (u32)(kg >> (q4 & 63)) & 0xFu;
+                if (keep) {
+                    u8* o = litOut + litBase + gexcl + popc64(kg & ((1ull << (q4 & 63)) - 1));
+                    const u32 v = *reinterpret_cast<const u32*>(L.in + p);
+                    if (keep == 0xFu) *(u32u*)o = v;
+                    else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
+                }
+                litBase += total;
+            }
+            nbSeq += nSel; cursor = lastEnd;
         }
+        t += nSub;
         ZMI_STAMP(7);
     }
 #ifdef ZMI_LZ_STAMPS
