@@ -153,7 +153,8 @@ __device__ __forceinline__ u32 next_match(const LzLds& L, u32 c, u32 par)
 // MODE 0 = fast (one 6-byte hash, levels 1-2); 1 = dual (8-byte + SHORT-byte hashes, four candidates per position,
 // levels 3-5: the place of U/ZstdDoubleFast.cs:51-247 and of the greedy row-hash search U/ZstdLazy.cs:1101-1309);
 // 2 = dual + one-step lazy deferral (levels >= 6: U/ZstdLazy.cs:1836-1905)
-template <int MODE, int SHORT>
+// DICT: a dictionary prefix is present (its bounds checks fold away otherwise)
+template <int MODE, int SHORT, bool DICT>
 __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
@@ -167,9 +168,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // are padding and never referenced).  History tiles run the probe/insert half of the loop only; the parse starts
     // with the cursor at `hist`, so everything after it is untouched: offsets simply reach back into the history.
     // chunkBytes = 64 KiB - hist (64 KiB without a dictionary).
-    const u32 hist = kChunkSize - chunkBytes, lowLimit = hist - prefixLen;
-    const u64 base = (u64)c * chunkBytes;
-    const u32 nData = (u32)((srcSize - base) < chunkBytes ? (srcSize - base) : chunkBytes);
+    const u32 hist = DICT ? kChunkSize - chunkBytes : 0u, lowLimit = DICT ? hist - prefixLen : 0u;
+    const u32 cb = DICT ? chunkBytes : kChunkSize;
+    const u64 base = (u64)c * cb;
+    const u32 nData = (u32)((srcSize - base) < cb ? (srcSize - base) : cb);
     const u32 n = hist + nData;                            // end of the data in LDS
     const u8* __restrict__ in = src + base;
 #ifdef ZMI_LZ_STAMPS
@@ -186,7 +188,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     } else {
         for (u32 i = tid; i < nData; i += kTile) L.in[hist + i] = in[i];
     }
-    for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
+    if (DICT) for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     u32* const endOf = reinterpret_cast<u32*>(L.jumpB);
     u32* const table = L.tabMem;                           // fast
@@ -257,7 +259,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     for (u32 t = 0, it = 0; t < nTiles; ++it) {
         const u32 tileStart = t * kTilePos;
         const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
-        const bool histTile = tileStart < hist;                                         // uniform: dictionary bytes, insert only
+        const bool histTile = DICT && tileStart < hist;                                         // uniform: dictionary bytes, insert only
         // Super-tile: where only every 2nd / 4th position is probed, TWO / FOUR tiles (as many as are left in full) are taken
         // in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies overlap and the
         // two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot (slot order = position
@@ -671,7 +673,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 }
 #endif
 
-template <int MODE, int SHORT>
+template <int MODE, int SHORT, bool DICT>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                        u32 chunkBytes, hipStream_t stream)
 {
@@ -679,10 +681,10 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
     static bool attrSet[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (!attrSet[dev & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -692,10 +694,18 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, hipStream_t stream)
 {
+    if (prefixLen == 0 || chunkBytes >= kChunkSize) {
+        switch (finder) {
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, stream); break;
+        }
+        return;
+    }
     switch (finder) {
-    case 0:  launch_one<0, 5>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
-    case 1:  launch_one<1, 5>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
-    default: launch_one<2, 5>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
     }
 }
 
