@@ -183,7 +183,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const uint4* in4 = reinterpret_cast<const uint4*>(in);
         uint4* l4 = reinterpret_cast<uint4*>(L.in + hist);
         const u32 full = nData >> 4;
-        for (u32 i = tid; i < full; i += kTile) l4[i] = in4[i];
+        if (full) {                                 // a full chunk is four 16-byte pieces per thread: all loads in flight, then the stores
+            uint4 v0, v1, v2, v3;                   // (pieces past the end re-read piece 0 and are not stored)
+            const u32 i0 = tid, i1 = tid + kTile, i2 = tid + 2 * kTile, i3 = tid + 3 * kTile;
+            v0 = in4[i0 < full ? i0 : 0]; v1 = in4[i1 < full ? i1 : 0]; v2 = in4[i2 < full ? i2 : 0]; v3 = in4[i3 < full ? i3 : 0];
+            if (i0 < full) l4[i0] = v0;
+            if (i1 < full) l4[i1] = v1;
+            if (i2 < full) l4[i2] = v2;
+            if (i3 < full) l4[i3] = v3;
+        }
         for (u32 i = (full << 4) + tid; i < nData; i += kTile) L.in[hist + i] = in[i];
     } else {
         for (u32 i = tid; i < nData; i += kTile) L.in[hist + i] = in[i];
@@ -197,9 +205,11 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u32* const firstS = L.tabMem + (1u << (kHashLog - 1));
     u16* const tableL = reinterpret_cast<u16*>(L.tabMem + (1u << kHashLog));
     u16* const tableS = tableL + (1u << kHashLog);
-    for (u32 i = tid; i < (1u << kHashLog); i += kTile) {
-        if (MODE == 0) { table[i] = 0; first[i] = 0xFFFFFFFFu; }
-        else           { L.tabMem[i] = 0xFFFFFFFFu; L.tabMem[(1u << kHashLog) + i] = 0; }
+    {   // fast: table = 0 (empty), first = ~0; dual: firstL|firstS = ~0, tableL|tableS = 0 — 32 KiB each, 16 bytes per store
+        uint4* const t4 = reinterpret_cast<uint4*>(L.tabMem);
+        const uint4 z = {0u, 0u, 0u, 0u}, f = {~0u, ~0u, ~0u, ~0u};
+#pragma unroll
+        for (u32 k = 0; k < 2; ++k) { t4[tid + k * kTile] = MODE == 0 ? z : f; t4[2 * kTile + tid + k * kTile] = MODE == 0 ? f : z; }
     }
     if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.nzWords[2] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; L.matchCount[2] = 0; }
     __syncthreads();
@@ -618,35 +628,41 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             litBase += span;
         } else {
             const u32 lastEnd = nSel ? endOf[nSel] : cursor;
-            for (u32 sub = 0; sub < nSub; ++sub) {
-                // Every wave scans the 64 group words itself (one LDS read per lane), so the compaction offsets need neither a
-                // cross-wave table nor another barrier.  keepG(g) = bytes of group g that are literals of this tile.
-                const u64* const cw = cov + sub * kGroups;
-                const u32 subStart = tileStart + sub * kTilePos;
-                const u32 c0s = c0 > sub * kTilePos ? c0 - sub * kTilePos : 0u;
-                auto keepG = [&](u32 g) -> u64 {
-                    const u32 g0 = g * 64;
-                    u64 k = ~cw[g];
-                    const u32 pG = subStart + g0;
-                    if (pG >= n) k = 0; else if (n - pG < 64) k &= (1ull << (n - pG)) - 1;
-                    if (c0s > g0) k = (c0s - g0 >= 64) ? 0ull : (k & (~0ull << (c0s - g0)));      // before the entry cursor: inside an earlier match
-                    return k;
-                };
-                const u32 gcnt = popc64(keepG(lane));
-                const u32 gincl = wave_scan_incl(gcnt);
-                const u32 total = read_lane(gincl, 63);
-                const u32 q4 = tid * 4, myG = q4 >> 6;           // 1024 threads cover 4096 positions, 4 each
-                const u32 p = subStart + q4;
-                const u64 kg = keepG(myG);
-                const u32 gexcl = __shfl(gincl - gcnt, (int)myG);
-                const u32 keep = (u32)(kg >> (q4 & 63)) & 0xFu;
+            // Every wave scans the group words itself (one LDS read per lane and sub-tile), so the compaction offsets need
+            // neither a cross-wave table nor another barrier.  keepG(sub, g) = bytes of group g of sub-tile `sub` that are
+            // literals.  The (up to four) sub-tiles of a super-tile are handled side by side: reads, scans, then stores.
+            auto keepG = [&](u32 sub, u32 g) -> u64 {
+                const u32 g0 = sub * kTilePos + g * 64;             // tile-relative
+                u64 k = ~cov[sub * kGroups + g];
+                const u32 pG = tileStart + g0;
+                if (pG >= n) k = 0; else if (n - pG < 64) k &= (1ull << (n - pG)) - 1;
+                if (c0 > g0) k = (c0 - g0 >= 64) ? 0ull : (k & (~0ull << (c0 - g0)));      // before the entry cursor: inside an earlier match
+                return k;
+            };
+            const u32 q4 = tid * 4, myG = q4 >> 6;           // 1024 threads cover 4096 positions, 4 each
+            u32 gcnt[4], gincl[4]; u64 kg[4];
+#pragma unroll
+            for (u32 sub = 0; sub < 4; ++sub) {
+                const bool on = sub < nSub;                  // uniform
+                gcnt[sub] = on ? popc64(keepG(sub, lane)) : 0u;
+                kg[sub] = on ? keepG(sub, myG) : 0ull;
+            }
+#pragma unroll
+            for (u32 sub = 0; sub < 4; ++sub) gincl[sub] = sub < nSub ? wave_scan_incl(gcnt[sub]) : 0u;
+#pragma unroll
+            for (u32 sub = 0; sub < 4; ++sub) {
+                if (sub < nSub) {                            // uniform
+                const u32 total = read_lane(gincl[sub], 63);
+                const u32 gexcl = __shfl(gincl[sub] - gcnt[sub], (int)myG);
+                const u32 keep = (u32)(kg[sub] >> (q4 & 63)) & 0xFu;
                 if (keep) {
-                    u8* o = litOut + litBase + gexcl + popc64(kg & ((1ull << (q4 & 63)) - 1));
-                    const u32 v = *reinterpret_cast<const u32*>(L.in + p);
+                    u8* o = litOut + litBase + gexcl + popc64(kg[sub] & ((1ull << (q4 & 63)) - 1));
+                    const u32 v = *reinterpret_cast<const u32*>(L.in + tileStart + sub * kTilePos + q4);
                     if (keep == 0xFu) *(u32u*)o = v;
                     else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
                 }
                 litBase += total;
+                }
             }
             nbSeq += nSel; cursor = lastEnd;
         }
