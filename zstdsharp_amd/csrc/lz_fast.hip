@@ -619,18 +619,20 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 nSel = any ? L.wordRank[64] : 0u;
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
         const u32 nSub = span >> kTileLog;          // 1, or 4 in a super-tile: the compaction below runs per 4096 positions
+        const u32 q16 = tid * 16;                   // sixteen positions per thread: a tile takes 256 threads, a super-tile up to 1024
         if (!any && c0 == 0 && tileStart + span <= n) {
             // nothing selected, nothing carried in, full tile: every byte is a literal, copied straight through
-            for (u32 sub = 0; sub < nSub; ++sub) {
-                const u32 q4 = sub * kTilePos + tid * 4;
-                *(u32u*)(litOut + litBase + q4) = *reinterpret_cast<const u32*>(L.in + tileStart + q4);
+            if (q16 < span) {
+                const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
+                u32u* o = (u32u*)(litOut + litBase + q16);
+                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
             }
             litBase += span;
         } else {
             const u32 lastEnd = nSel ? endOf[nSel] : cursor;
             // Every wave scans the group words itself (one LDS read per lane and sub-tile), so the compaction offsets need
             // neither a cross-wave table nor another barrier.  keepG(sub, g) = bytes of group g of sub-tile `sub` that are
-            // literals.  The (up to four) sub-tiles of a super-tile are handled side by side: reads, scans, then stores.
+            // literals.  The (up to four) sub-tiles of a super-tile are scanned side by side.
             auto keepG = [&](u32 sub, u32 g) -> u64 {
                 const u32 g0 = sub * kTilePos + g * 64;             // tile-relative
                 u64 k = ~cov[sub * kGroups + g];
@@ -639,31 +641,35 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 if (c0 > g0) k = (c0 - g0 >= 64) ? 0ull : (k & (~0ull << (c0 - g0)));      // before the entry cursor: inside an earlier match
                 return k;
             };
-            const u32 q4 = tid * 4, myG = q4 >> 6;           // 1024 threads cover 4096 positions, 4 each
-            u32 gcnt[4], gincl[4]; u64 kg[4];
+            u32 gcnt[4], gincl[4];
 #pragma unroll
-            for (u32 sub = 0; sub < 4; ++sub) {
-                const bool on = sub < nSub;                  // uniform
-                gcnt[sub] = on ? popc64(keepG(sub, lane)) : 0u;
-                kg[sub] = on ? keepG(sub, myG) : 0ull;
-            }
+            for (u32 sub = 0; sub < 4; ++sub) gcnt[sub] = sub < nSub ? popc64(keepG(sub, lane)) : 0u;       // (uniform predicate)
 #pragma unroll
             for (u32 sub = 0; sub < 4; ++sub) gincl[sub] = sub < nSub ? wave_scan_incl(gcnt[sub]) : 0u;
+            const u32 tot0 = read_lane(gincl[0], 63), tot1 = read_lane(gincl[1], 63), tot2 = read_lane(gincl[2], 63), tot3 = read_lane(gincl[3], 63);
+            if (q16 < span) {                                // whole waves: 256 threads per sub-tile
+                const u32 mySub = tid >> 8, gl = (tid >> 2) & 63u, sh = (tid & 3u) * 16u;
+                const u32 myExcl = mySub == 0 ? gincl[0] - gcnt[0] : mySub == 1 ? gincl[1] - gcnt[1] : mySub == 2 ? gincl[2] - gcnt[2] : gincl[3] - gcnt[3];
+                const u32 subBase = mySub == 0 ? 0u : mySub == 1 ? tot0 : mySub == 2 ? tot0 + tot1 : tot0 + tot1 + tot2;
+                const u32 gexcl = __shfl(myExcl, (int)gl);
+                const u64 kgw = keepG(mySub, gl);
+                const u32 keep16 = (u32)(kgw >> sh) & 0xFFFFu;
+                if (keep16) {
+                    u8* o = litOut + litBase + subBase + gexcl + popc64(kgw & ((1ull << sh) - 1));
+                    const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
+                    if (keep16 == 0xFFFFu) { u32u* o4 = (u32u*)o; o4[0] = v.x; o4[1] = v.y; o4[2] = v.z; o4[3] = v.w; }
+                    else {
+                        const u32 d[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-            for (u32 sub = 0; sub < 4; ++sub) {
-                if (sub < nSub) {                            // uniform
-                const u32 total = read_lane(gincl[sub], 63);
-                const u32 gexcl = __shfl(gincl[sub] - gcnt[sub], (int)myG);
-                const u32 keep = (u32)(kg[sub] >> (q4 & 63)) & 0xFu;
-                if (keep) {
-                    u8* o = litOut + litBase + gexcl + popc64(kg[sub] & ((1ull << (q4 & 63)) - 1));
-                    const u32 v = *reinterpret_cast<const u32*>(L.in + tileStart + sub * kTilePos + q4);
-                    if (keep == 0xFu) *(u32u*)o = v;
-                    else { if (keep & 1) *o++ = (u8)v; if (keep & 2) *o++ = (u8)(v >> 8); if (keep & 4) *o++ = (u8)(v >> 16); if (keep & 8) *o++ = (u8)(v >> 24); }
-                }
-                litBase += total;
+                        for (u32 k = 0; k < 4; ++k) {
+                            const u32 keep = (keep16 >> (4 * k)) & 0xFu, w4 = d[k];
+                            if (keep == 0xFu) { *(u32u*)o = w4; o += 4; }
+                            else { if (keep & 1) *o++ = (u8)w4; if (keep & 2) *o++ = (u8)(w4 >> 8); if (keep & 4) *o++ = (u8)(w4 >> 16); if (keep & 8) *o++ = (u8)(w4 >> 24); }
+                        }
+                    }
                 }
             }
+            litBase += tot0 + tot1 + tot2 + tot3;
             nbSeq += nSel; cursor = lastEnd;
         }
         t += nSub;
