@@ -232,7 +232,22 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const u32 litStart = endOf[rank];
         const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
         // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
-        while (p > floorPos && p > off + lowLimit && L.in[p - 1] == L.in[p - off - 1]) --p;
+        // (four bytes per step: the dwords in front of the match and of its source, compared from the top)
+        for (;;) {
+            u32 room = p - floorPos;                                   // bytes the pending literal run can give
+            const u32 srcRoom = p - off - lowLimit;                    // bytes in front of the source
+            if (srcRoom < room) room = srcRoom;
+            if (room == 0) break;
+            if (p - off < 4) {                                         // source within 4 bytes of the start: byte steps
+                if (L.in[p - 1] != L.in[p - off - 1]) break;
+                --p; continue;
+            }
+            const u32 x = lds_load4(L.in, p - 4) ^ lds_load4(L.in, p - off - 4);
+            u32 m = x ? (u32)__builtin_clz(x) >> 3 : 4u;               // byte p-1 is the dword's top byte
+            if (m > room) m = room;
+            p -= m;
+            if (m < 4) break;
+        }
         Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(p - litStart); sq.mlBase = (u16)(end - p - 3);
         seqOut[nbSeq + rank] = sq;
         const u32 r0 = p - tileStart, r1 = (end - tileStart) < span ? (end - tileStart) : span;
