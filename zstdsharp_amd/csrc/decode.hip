@@ -778,7 +778,7 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
 // 2.4 KiB per frame -> 64 frames per CU -> one round.  Same acceptance as the other forms; tableLog 12 goes the slow way.
 // =====================================================================================================================
 struct CompactLds {
-    u16 huf[1024];              // byte | nbBits << 8 (entries owned by 11-bit codes are unused).  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
+    u16 huf[1024];              // byte | nbBits << 8; the first n1/2 entries (owned by pairs of 11-bit codes): symbol(bit 0) | symbol(bit 1) << 8.  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
     u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded; its head = the 11-bit codes in table order
     u32 classStart[14];         // first index (in the tableLog-bit table) of weight class w; [tableLog + 1] = table size
     u32 classFirst[14];         // index into sorted[] of the first symbol of class w
@@ -786,8 +786,8 @@ struct CompactLds {
 };
 
 // n1 = number of 11-bit codes when tableLog = 11 (else 0).  In the canonical order (HUF_readDTableX1: weight classes ascending)
-// they own the first n1 entries of the 11-bit table, one each, so "the next 11 bits < n1" identifies them and indexes `sorted`
-// directly: the symbol read and the 10-bit table read are issued together and one select picks — a single LDS latency per
+// they own the first n1 entries of the 11-bit table, one each, i.e. the first n1/2 entries of the 10-bit table, two each: such
+// an entry holds BOTH symbols (low byte: next bit 0, high byte: next bit 1) and "index < n1/2" says so.  One LDS read per
 // symbol whatever the code length, no branch.
 __device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ table, const u8* __restrict__ sorted, u32 tableLog, u32 n1,
                                                     const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
@@ -795,11 +795,14 @@ __device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ tabl
     if (srcSize < 1) return false;
     const u32 idxBits = tableLog > 10 ? 10u : tableLog;
     s32 remaining; u32 i = 0;
+    const u32 nPair = n1 >> 1;
+    (void)sorted;
     auto lookup = [&](u32 top32) -> u32 {                 // top32 = the next 32 stream bits
-        const u32 top = top32 >> (31 - idxBits);          // idxBits + 1 bits
-        const u32 e10 = table[top >> 1];
-        const u32 e1 = sorted[top & 255u];
-        return top < n1 ? (e1 | (11u << 8)) : e10;
+        const u32 idx = top32 >> (32 - idxBits);
+        const u32 sh = (top32 >> 18) & 8u;                // 8 x the bit after the 10 index bits (only used when tableLog = 11)
+        const u32 e = table[idx];
+        const u32 pairSym = ((e >> sh) & 0xFFu) | (11u << 8);
+        return idx < nPair ? pairSym : e;
     };
     if (srcSize >= 16) {
         s32 ptr = (s32)srcSize - 8;
@@ -912,7 +915,10 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                                 for (u32 cw = 2; cw <= tableLog; ++cw) if (Q.classFirst[cw] <= k) w = cw;
                                 const u32 start = Q.classStart[w] + ((k - Q.classFirst[w]) << (w - 1));     // index in the tableLog-bit table
                                 const u32 sym = Q.sorted[k];
-                                if (drop && w == 1) continue;           // 11-bit codes are read from `sorted` (see huf_decode_stream4c)
+                                if (drop && w == 1) {                   // 11-bit codes: both symbols of the pair in one entry (see huf_decode_stream4c)
+                                    if (!(start & 1)) Q.huf[start >> 1] = (u16)(sym | ((u32)Q.sorted[k + 1] << 8));
+                                    continue;
+                                }
                                 const u32 len = ((1u << w) >> 1) >> drop, st = start >> drop;
                                 const u32 e = sym | ((tableLog + 1 - w) << 8);
                                 if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
