@@ -233,3 +233,65 @@ def test_dictionary_compression_is_deterministic(gpu_lib):
         first = c.Wrap(data)
         for _ in range(3):
             assert c.Wrap(data) == first
+
+
+def test_corrupted_dictionary_frames_fail_cleanly(gpu_lib, oracle):
+    """Bit flips, overwrites and truncations of dictionary frames, decoded WITH the dictionary: an error or bytes, never a
+    fault; whenever the oracle's dictionary decoder accepts the damaged frame, both must produce the same bytes (offsets that
+    point beyond dictionary + produced bytes are corruption_detected on both sides, U/ZstdDecompressBlock.cs:2223-2230)."""
+    import random
+    rng = random.Random(77)
+    dic = build_dictionary(6000, 4)
+    seeds = []
+    for n in (300, 5000, 70000):
+        data = words_text(n, n + 5)
+        seeds.append((oracle.compress_dict(data, dic, 1, 1), n))
+        seeds.append((oracle.compress_dict(data, dic, 1, 0), n))
+    with z.Compressor(1) as c:
+        c.LoadDictionary(dic)
+        data = words_text(40000, 2)
+        seeds.append((c.Wrap(data), len(data)))
+    agree = errors = 0
+    with z.Decompressor() as d:
+        d.LoadDictionary(dic)
+        for blob, n in seeds:
+            for _ in range(40):
+                b = bytearray(blob)
+                mode = rng.randrange(3)
+                if mode == 0:
+                    i = rng.randrange(len(b)); b[i] ^= 1 << rng.randrange(8)
+                elif mode == 1:
+                    i = rng.randrange(len(b)); b[i] = rng.randrange(256)
+                else:
+                    del b[rng.randrange(4, len(b)):]
+                b = bytes(b)
+                want = oracle.decompress(b, n + 4096, dic)
+                dest = bytearray(n + 4096)
+                try:
+                    got = d.Unwrap(b, dest)
+                    out = bytes(dest[:got])
+                except ZstdException:
+                    out = None
+                if isinstance(want, int):
+                    errors += out is None
+                else:
+                    assert out == want, "the decoders disagree on a dictionary frame the oracle accepts"
+                    agree += 1
+    assert errors > 60
+
+
+def test_frames_without_content_size_with_dictionary(gpu_lib, oracle):
+    """unsized frames (window descriptor instead of the content size, as the reference's streaming compressor writes them)
+    whose matches reach into the dictionary: decoded into bound-sized slots and compacted, like their dictionary-less kind"""
+    from test_gpu_parity import _strip_content_size
+    dic = build_dictionary(3000, 8)
+    parts = [words_text(m, m + 2) for m in (500, 20000, 90000)]
+    blob = b"".join(_strip_content_size(oracle.compress_dict(p, dic, 1, 1), len(p)) for p in parts)
+    for p in parts:
+        one = _strip_content_size(oracle.compress_dict(p, dic, 1, 1), len(p))
+        assert oracle.decompress(one, len(p), dic) == p                    # the rewritten frame is valid zstd
+    with z.Decompressor() as d:
+        d.LoadDictionary(dic)
+        dest = bytearray(gpu_lib.ZSTD_decompressBound(blob, len(blob)))
+        got = d.Unwrap(blob, dest)
+        assert bytes(dest[:got]) == b"".join(parts)
