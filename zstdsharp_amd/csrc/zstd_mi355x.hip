@@ -216,20 +216,22 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         const u64 n = (srcSize - c0 * chunkBytes) < (u64)nChunks * chunkBytes ? (srcSize - c0 * chunkBytes) : (u64)nChunks * chunkBytes;
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
-        if (first) c->timer.begin(s);
-        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, s);                      if (first) c->timer.mark("lz_fast", s);
-        launch_huf_build(lits, meta, tables, slots, nChunks, s);                        if (first) c->timer.mark("huf_build", s);
-        if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             if (first) c->timer.mark("xxh64", s); }
-        launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, s);   if (first) c->timer.mark("seq_encode", s);
-        launch_scan_sizes(meta, nChunks, offsets, total, s);                       if (first) c->timer.mark("scan", s);
+        c->timer.begin(s);
+        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, s);                      c->timer.mark("lz_fast", s);
+        launch_huf_build(lits, meta, tables, slots, nChunks, s);                        c->timer.mark("huf_build", s);
+        if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             c->timer.mark("xxh64", s); }
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, s);   c->timer.mark("seq_encode", s);
+        launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
-        launch_huf_encode(lits, meta, tables, slots, d_dst + produced, offsets, room, nChunks, s);   if (first) c->timer.mark("huf_encode", s);
-        launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, chunkBytes, s);      if (first) c->timer.mark("gather", s);
+        launch_huf_encode(lits, meta, tables, slots, d_dst + produced, offsets, room, nChunks, s);   c->timer.mark("huf_encode", s);
+        launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, chunkBytes, s);      c->timer.mark("gather", s);
         u64 passTotal = 0;
         if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
         if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-        if (first) { c->timer.finish(); c->nStages = c->timer.n; for (int i = 0; i < c->timer.n; i++) { c->stageMs[i] = c->timer.ms[i]; c->stageNames[i] = c->timer.names[i]; } }
+        // stage times of the call = sums over its passes (inputs above 1 GiB take several)
+        c->timer.finish(); c->nStages = c->timer.n;
+        for (int i = 0; i < c->timer.n; i++) { c->stageMs[i] = (first ? 0.f : c->stageMs[i]) + c->timer.ms[i]; c->stageNames[i] = c->timer.names[i]; }
         first = false;
         if (passTotal > room) return ZERR(kErrDstSizeTooSmall);
         produced += (size_t)passTotal;
