@@ -103,6 +103,9 @@ u64 zso_xxh64(const void* data, size_t len, u64 seed);
 
 /* decoder (zso_dec.c) */
 size_t zso_decompress(void* dst, size_t dstCapacity, const void* src, size_t srcSize);
+/* shared by the dictionary loaders of both sides (FSE_readNCount, U/EntropyCommon.cs:60-250; HUF_readStats, :292-402) */
+size_t zso_readNCount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const void* src, size_t srcSize);
+size_t zso_huf_readStats(u8* weights, u32* nbSymbolsPtr, u32* tableLogPtr, u32* rankStats, const void* src, size_t srcSize);
 size_t zso_decompress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* dict, size_t dictSize);
 u64    zso_decompressBound(const void* src, size_t srcSize);
 u64    zso_getFrameContentSize(const void* src, size_t srcSize);

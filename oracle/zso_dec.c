@@ -63,7 +63,7 @@ static inline u32 fwd_bits(const u8* p, size_t size, size_t bitpos, u32 n)
 }
 
 /* FSE_readNCount_body, U/EntropyCommon.cs:52-242 */
-static size_t zso_readNCount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const void* src, size_t srcSize)
+size_t zso_readNCount(s16* norm, u32* maxSVPtr, u32* tableLogPtr, const void* src, size_t srcSize)
 {
     const u8* ip = (const u8*)src;
     size_t bitpos = 0;
@@ -189,7 +189,7 @@ typedef struct { u8 byte; u8 nbBits; } zso_huf_dentry;
 typedef struct { u32 tableLog; zso_huf_dentry e[1 << 12]; int valid; } zso_huf_dtable;
 
 /* HUF_readStats_body, U/EntropyCommon.cs:292-402.  Returns bytes consumed. */
-static size_t zso_huf_readStats(u8* weights, u32* nbSymbolsPtr, u32* tableLogPtr, u32* rankStats,
+size_t zso_huf_readStats(u8* weights, u32* nbSymbolsPtr, u32* tableLogPtr, u32* rankStats,
                                 const void* src, size_t srcSize)
 {
     const u8* ip = (const u8*)src;
@@ -334,7 +334,10 @@ typedef struct {
     int llValid, ofValid, mlValid;
     zso_huf_dtable huf;
     u32 rep[3];
-    const u8* dict; size_t dictSize;  /* raw-content dictionary = history in front of every frame (ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771) */
+    const u8* dict; size_t dictSize;  /* dictionary CONTENT = history in front of every frame (ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771) */
+    /* formatted dictionary (ZSTD_loadDEntropy, :1773-1875): entropy tables and repcodes every frame starts from */
+    int dictEntropy; u32 dictID; u32 dictRep[3];
+    zso_seqtable dLL, dOF, dML; zso_huf_dtable dHuf;
 } zso_frame_state;
 
 /* ZSTD_buildSeqTable, U/ZstdDecompressBlock.cs:1746-1840.  Returns bytes consumed. */
@@ -366,6 +369,45 @@ static size_t zso_setSeqTable(zso_seqtable* t, int* valid, u32 type, u32 max, u3
         *valid = 1;
         return hs; }
     }
+}
+
+/* ZSTD_loadDEntropy, U/ZstdDecompress.cs:1773-1875: Huffman table, then the offset, match-length and literal-length
+ * NCounts, then three repcodes; returns the size of this header (content follows) or dictionary_corrupted. */
+static size_t zso_loadDEntropy(zso_frame_state* fs, const u8* dict, size_t dictSize)
+{
+    const u8* p = dict + 8; const u8* const end = dict + dictSize;
+    if (dictSize <= 8) return ZSO_ERR(dictionary_corrupted);
+    {   size_t const h = zso_huf_readDTable(&fs->dHuf, p, (size_t)(end - p));
+        if (zso_isError(h)) return ZSO_ERR(dictionary_corrupted);
+        p += h;
+    }
+    {   s16 norm[64]; u32 maxSV = 31, log;
+        size_t const h = zso_readNCount(norm, &maxSV, &log, p, (size_t)(end - p));
+        if (zso_isError(h) || maxSV > 31 || log > 8) return ZSO_ERR(dictionary_corrupted);
+        zso_buildSeqTable(&fs->dOF, norm, maxSV, ZSO_OF_base, ZSO_OF_bits, log);
+        p += h;
+    }
+    {   s16 norm[64]; u32 maxSV = 52, log;
+        size_t const h = zso_readNCount(norm, &maxSV, &log, p, (size_t)(end - p));
+        if (zso_isError(h) || maxSV > 52 || log > 9) return ZSO_ERR(dictionary_corrupted);
+        zso_buildSeqTable(&fs->dML, norm, maxSV, ZSO_ML_base, ZSO_ML_bits, log);
+        p += h;
+    }
+    {   s16 norm[64]; u32 maxSV = 35, log;
+        size_t const h = zso_readNCount(norm, &maxSV, &log, p, (size_t)(end - p));
+        if (zso_isError(h) || maxSV > 35 || log > 9) return ZSO_ERR(dictionary_corrupted);
+        zso_buildSeqTable(&fs->dLL, norm, maxSV, ZSO_LL_base, ZSO_LL_bits, log);
+        p += h;
+    }
+    if (p + 12 > end) return ZSO_ERR(dictionary_corrupted);
+    {   size_t const contentSize = (size_t)(end - (p + 12)); int i;
+        for (i = 0; i < 3; i++) {
+            u32 const r = zso_readLE32(p); p += 4;
+            if (r == 0 || r > contentSize) return ZSO_ERR(dictionary_corrupted);
+            fs->dictRep[i] = r;
+        }
+    }
+    return (size_t)(p - dict);
 }
 
 /* ---------- block decode (U/ZstdDecompressBlock.cs:3090-3154) ---------- */
@@ -642,12 +684,17 @@ static size_t zso_decompressFrame(u8* dst, size_t dstCapacity, const u8** srcPtr
         r = zso_getFrameHeader(&h, ip, fhs);
         if (zso_isError(r)) return r;
         if (r > 0) return ZSO_ERR(srcSize_wrong);
-        if (h.dictID) return ZSO_ERR(dictionary_wrong);
+        if (h.dictID && h.dictID != fs->dictID) return ZSO_ERR(dictionary_wrong);      /* :1404-1412 */
         ip += fhs; remaining -= fhs;
     }
-    /* ZSTD_decompressBegin, :1933-1954: fresh entropy state and repcodes per frame */
+    /* ZSTD_decompressBegin(_usingDict), :1933-1990: fresh entropy state and repcodes per frame, or the dictionary's */
     fs->llValid = fs->ofValid = fs->mlValid = 0; fs->huf.valid = 0;
     fs->rep[0] = 1; fs->rep[1] = 4; fs->rep[2] = 8;
+    if (fs->dictEntropy) {
+        fs->LL = fs->dLL; fs->OF = fs->dOF; fs->ML = fs->dML; fs->huf = fs->dHuf;
+        fs->llValid = fs->ofValid = fs->mlValid = 1; fs->huf.valid = 1;
+        fs->rep[0] = fs->dictRep[0]; fs->rep[1] = fs->dictRep[1]; fs->rep[2] = fs->dictRep[2];
+    }
     for (;;) {
         u32 bh, last, type, cSize; size_t decoded;
         if (remaining < 3) return ZSO_ERR(srcSize_wrong);
@@ -690,9 +737,8 @@ size_t zso_decompress(void* dst, size_t dstCapacity, const void* src, size_t src
     return zso_decompress_usingDict(dst, dstCapacity, src, srcSize, NULL, 0);
 }
 
-/* ZSTD_decompress_usingDict with a RAW-CONTENT dictionary (no magic: ZSTD_decompress_insertDictionary falls through to
- * ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771, 1909-1931).  A dictionary that starts with the dictionary magic
- * carries entropy tables, which this oracle does not restate: refused. */
+/* ZSTD_decompress_usingDict (ZSTD_decompress_insertDictionary, U/ZstdDecompress.cs:1909-1931): without the magic the bytes
+ * are raw content (ZSTD_refDictContent, :1758-1771); with it, dictID + entropy tables + repcodes precede the content. */
 size_t zso_decompress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize, const void* dict, size_t dictSize)
 {
     const u8* ip = (const u8*)src; u8* op = (u8*)dst;
@@ -701,8 +747,14 @@ size_t zso_decompress_usingDict(void* dst, size_t dstCapacity, const void* src, 
     u8* litBuf = (u8*)malloc(ZSO_BLOCKSIZE_MAX + 64);
     size_t result = 0;
     if (!fs || !litBuf) { free(fs); free(litBuf); return ZSO_ERR(memory_allocation); }
-    if (dictSize >= 8 && zso_readLE32(dict) == 0xEC30A437u) { free(fs); free(litBuf); return ZSO_ERR(parameter_unsupported); }
-    fs->dict = (const u8*)dict; fs->dictSize = dict ? dictSize : 0;
+    fs->dict = (const u8*)dict; fs->dictSize = dict ? dictSize : 0; fs->dictEntropy = 0; fs->dictID = 0;
+    if (dict && dictSize >= 8 && zso_readLE32(dict) == 0xEC30A437u) {
+        size_t const e = zso_loadDEntropy(fs, (const u8*)dict, dictSize);
+        if (zso_isError(e)) { free(fs); free(litBuf); return e; }
+        fs->dictID = zso_readLE32((const u8*)dict + 4);
+        fs->dictEntropy = 1;
+        fs->dict = (const u8*)dict + e; fs->dictSize = dictSize - e;
+    }
     while (srcSize >= 5) {
         u32 const magic = zso_readLE32(ip);
         if ((magic & 0xFFFFFFF0u) == ZSO_MAGIC_SKIPPABLE) {

@@ -1261,17 +1261,24 @@ static size_t zso_compressBlock_lazy_row(zso_mstate* ms, zso_seqstore* ss, u32 r
 /* ------------------------------------------------------------------ */
 /*  frame                                                              */
 /* ------------------------------------------------------------------ */
-/* ZSTD_writeFrameHeader, U/ZstdCompress.cs:4817-4929 (no dictID, contentSizeFlag = 1) */
-static size_t zso_writeFrameHeader(u8* op, size_t cap, u32 windowLog, u64 pledged, int checksumFlag)
+/* ZSTD_writeFrameHeader, U/ZstdCompress.cs:4817-4929 (contentSizeFlag = 1; dictID 0 = none) */
+static size_t zso_writeFrameHeader(u8* op, size_t cap, u32 windowLog, u64 pledged, int checksumFlag, u32 dictID)
 {
     u32 const windowSize = 1u << windowLog;
     u32 const single = windowSize >= pledged;
     u32 const fcsCode = (pledged >= 256) + (pledged >= 65536 + 256) + (pledged >= 0xFFFFFFFFu);
+    u32 const didCode = (dictID > 0) + (dictID >= 256) + (dictID >= 65536);
     size_t pos = 0;
     if (cap < 18) return ZSO_ERR(dstSize_tooSmall);
     zso_writeLE32(op, ZSO_MAGIC); pos = 4;
-    op[pos++] = (u8)(0 + ((u32)(checksumFlag > 0) << 2) + (single << 5) + (fcsCode << 6));
+    op[pos++] = (u8)(didCode + ((u32)(checksumFlag > 0) << 2) + (single << 5) + (fcsCode << 6));
     if (!single) op[pos++] = (u8)((windowLog - 10) << 3);
+    switch (didCode) {
+    case 1: op[pos++] = (u8)dictID; break;
+    case 2: zso_writeLE16(op + pos, dictID); pos += 2; break;
+    case 3: zso_writeLE32(op + pos, dictID); pos += 4; break;
+    default: break;
+    }
     switch (fcsCode) {
     case 0: if (single) op[pos++] = (u8)pledged; break;
     case 1: zso_writeLE16(op + pos, (u32)(pledged - 256)); pos += 2; break;
@@ -1310,8 +1317,84 @@ static size_t zso_blockCompressor(zso_mstate* ms, zso_seqstore* ss, u32 rep[3], 
  * attach/copy path `ZSTD_CCtx_loadDictionary` + `ZSTD_compress2` would take (dictMatchState / extDict finders, which
  * this oracle does not restate): the frames are valid dictionary frames for DECODER tests; their bytes are
  * "parity unpinned" (the reference holds no dictionary fixtures — its tests train dictionaries at run time). */
+/* HUF_readCTable, U/HufCompress.cs:237-290: weights -> code lengths -> canonical codes; *hasZeroWeights as the reference reports it */
+static size_t zso_huf_readCTable(zso_huf_ct* ct, u32* maxSVPtr, const void* src, size_t srcSize, u32* hasZeroWeights)
+{
+    u8 weights[256]; u32 rankStats[13], nbSymbols = 0, tableLog = 0, n; u16 nbPerRank[14] = {0}, valPerRank[14] = {0};
+    size_t const readSize = zso_huf_readStats(weights, &nbSymbols, &tableLog, rankStats, src, srcSize);
+    if (zso_isError(readSize)) return readSize;
+    if (tableLog > 12) return ZSO_ERR(tableLog_tooLarge);
+    if (nbSymbols > *maxSVPtr + 1) return ZSO_ERR(maxSymbolValue_tooSmall);
+    memset(ct->nbBits, 0, sizeof ct->nbBits); memset(ct->val, 0, sizeof ct->val);
+    *hasZeroWeights = 0;
+    for (n = 0; n < nbSymbols; n++) {
+        u32 const w = weights[n];
+        *hasZeroWeights |= (w == 0);
+        ct->nbBits[n] = (u8)((tableLog + 1 - w) & -(int)(w != 0));
+    }
+    for (n = 0; n < nbSymbols; n++) nbPerRank[ct->nbBits[n]]++;
+    valPerRank[tableLog + 1] = 0;
+    {   u16 min = 0; u32 r;
+        for (r = tableLog; r > 0; r--) { valPerRank[r] = min; min += nbPerRank[r]; min >>= 1; }
+    }
+    for (n = 0; n < nbSymbols; n++) ct->val[n] = valPerRank[ct->nbBits[n]]++;
+    ct->tableLog = tableLog; ct->maxSV = nbSymbols - 1; ct->valid = 1;
+    *maxSVPtr = nbSymbols - 1;
+    return readSize;
+}
+
+/* ZSTD_dictNCountRepeat, U/ZstdCompress.cs:5239-5257 */
+static int zso_dictNCountRepeat(const s16* norm, u32 dictMaxSV, u32 maxSV)
+{
+    u32 s;
+    if (dictMaxSV < maxSV) return FSE_repeat_check;
+    for (s = 0; s <= maxSV; s++) if (norm[s] == 0) return FSE_repeat_check;
+    return FSE_repeat_valid;
+}
+
+/* ZSTD_loadCEntropy, U/ZstdCompress.cs:5259-5400.  Returns the size of the dictionary's header (content follows). */
+static size_t zso_loadCEntropy(zso_bstate* bs, const u8* dict, size_t dictSize)
+{
+    const u8* p = dict + 8; const u8* const end = dict + dictSize;
+    s16 ofNorm[64], mlNorm[64], llNorm[64]; u32 ofMax = 31, mlMax = 52, llMax = 35, log;
+    bs->hufRepeat = HUF_repeat_check;
+    {   u32 maxSV = 255, hasZero = 1;
+        size_t const h = zso_huf_readCTable(&bs->huf, &maxSV, p, (size_t)(end - p), &hasZero);
+        if (!hasZero) bs->hufRepeat = HUF_repeat_valid;
+        if (zso_isError(h) || maxSV < 255) return ZSO_ERR(dictionary_corrupted);
+        p += h;
+    }
+    {   size_t const h = zso_readNCount(ofNorm, &ofMax, &log, p, (size_t)(end - p));
+        if (zso_isError(h) || log > 8) return ZSO_ERR(dictionary_corrupted);
+        if (zso_isError(zso_fse_buildCTable(&bs->of, ofNorm, 31, log))) return ZSO_ERR(dictionary_corrupted);
+        p += h;
+    }
+    {   size_t const h = zso_readNCount(mlNorm, &mlMax, &log, p, (size_t)(end - p));
+        if (zso_isError(h) || log > 9) return ZSO_ERR(dictionary_corrupted);
+        if (zso_isError(zso_fse_buildCTable(&bs->ml, mlNorm, mlMax, log))) return ZSO_ERR(dictionary_corrupted);
+        bs->mlRepeat = zso_dictNCountRepeat(mlNorm, mlMax, 52);
+        p += h;
+    }
+    {   size_t const h = zso_readNCount(llNorm, &llMax, &log, p, (size_t)(end - p));
+        if (zso_isError(h) || log > 9) return ZSO_ERR(dictionary_corrupted);
+        if (zso_isError(zso_fse_buildCTable(&bs->ll, llNorm, llMax, log))) return ZSO_ERR(dictionary_corrupted);
+        bs->llRepeat = zso_dictNCountRepeat(llNorm, llMax, 35);
+        p += h;
+    }
+    if (p + 12 > end) return ZSO_ERR(dictionary_corrupted);
+    bs->rep[0] = zso_readLE32(p); bs->rep[1] = zso_readLE32(p + 4); bs->rep[2] = zso_readLE32(p + 8);
+    p += 12;
+    {   size_t const contentSize = (size_t)(end - p); u32 offcodeMax = 31, u;
+        if (contentSize <= 0xFFFFFFFFu - (128u << 10)) offcodeMax = zso_highbit32((u32)contentSize + (128u << 10));
+        bs->ofRepeat = zso_dictNCountRepeat(ofNorm, ofMax, offcodeMax < 31 ? offcodeMax : 31);
+        for (u = 0; u < 3; u++) if (bs->rep[u] == 0 || bs->rep[u] > contentSize) return ZSO_ERR(dictionary_corrupted);
+    }
+    return (size_t)(p - dict);
+}
+
+/* entropyDict != NULL: a formatted dictionary's header (magic, dictID, tables, repcodes); its content is the prefix */
 static size_t zso_compress_internal(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksumFlag,
-                                    size_t prefixLen)
+                                    size_t prefixLen, const u8* entropyDict, size_t entropyDictSize)
 {
     zso_cparams const cp = zso_getCParams(level, srcSize + prefixLen);
     u8* const ostart = (u8*)dst; u8* op = ostart; const u8* ip = (const u8*)src; size_t remaining = srcSize;
@@ -1323,7 +1406,7 @@ static size_t zso_compress_internal(void* dst, size_t dstCapacity, const void* s
        the hash-chain finder of the small-window tiers is not restated: say so, never substitute */
     if (cp.strategy >= ZSO_greedy && cp.windowLog <= 14) return ZSO_ERR(parameter_unsupported);
     if (prefixLen && cp.strategy != ZSO_fast) return ZSO_ERR(parameter_unsupported);
-    {   size_t const h = zso_writeFrameHeader(op, dstCapacity, cp.windowLog, srcSize, checksumFlag);
+    {   size_t const h = zso_writeFrameHeader(op, dstCapacity, cp.windowLog, srcSize, checksumFlag, entropyDict ? zso_readLE32(entropyDict + 4) : 0);
         if (zso_isError(h)) return h;
         op += h; dstCapacity -= h;
     }
@@ -1341,6 +1424,10 @@ static size_t zso_compress_internal(void* dst, size_t dstCapacity, const void* s
     seqstore_alloc(&ss, blockSize);
     prev = (zso_bstate*)malloc(sizeof *prev); next = (zso_bstate*)malloc(sizeof *next);
     bstate_reset(prev); bstate_reset(next);
+    if (entropyDict) {
+        size_t const e = zso_loadCEntropy(prev, entropyDict, entropyDictSize);
+        if (zso_isError(e)) { result = e; goto done; }
+    }
     while (remaining) {             /* ZSTD_compress_frameChunk */
         u32 const lastBlock = blockSize >= remaining;
         u32 const maxDist = 1u << cp.windowLog;
@@ -1403,7 +1490,7 @@ done:
 
 size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level, int checksumFlag)
 {
-    return zso_compress_internal(dst, dstCapacity, src, srcSize, level, checksumFlag, 0);
+    return zso_compress_internal(dst, dstCapacity, src, srcSize, level, checksumFlag, 0, NULL, 0);
 }
 
 size_t zso_compress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
@@ -1411,11 +1498,22 @@ size_t zso_compress_usingDict(void* dst, size_t dstCapacity, const void* src, si
 {
     u8* buf; size_t r;
     if (dict == NULL || dictSize < 8) return zso_compress(dst, dstCapacity, src, srcSize, level, checksumFlag);   /* :5469-5477 */
-    if (zso_readLE32(dict) == 0xEC30A437u) return ZSO_ERR(parameter_unsupported);     /* formatted dictionary: entropy tables not restated */
     buf = (u8*)malloc(dictSize + srcSize + 8);
     if (!buf) return ZSO_ERR(memory_allocation);
     memcpy(buf, dict, dictSize); memcpy(buf + dictSize, src, srcSize); memset(buf + dictSize + srcSize, 0, 8);
-    r = zso_compress_internal(dst, dstCapacity, buf + dictSize, srcSize, level, checksumFlag, dictSize);
+    if (zso_readLE32(dict) == 0xEC30A437u) {
+        /* formatted dictionary (ZSTD_loadZstdDictionary, :5402-5463): the header's tables and repcodes become the previous
+           block state, the content behind it the prefix */
+        zso_bstate* probe = (zso_bstate*)malloc(sizeof *probe);
+        size_t e;
+        if (!probe) { free(buf); return ZSO_ERR(memory_allocation); }
+        bstate_reset(probe);
+        e = zso_loadCEntropy(probe, (const u8*)dict, dictSize);
+        free(probe);
+        if (zso_isError(e)) { free(buf); return e; }
+        r = zso_compress_internal(dst, dstCapacity, buf + dictSize, srcSize, level, checksumFlag, dictSize - e, buf, dictSize);
+    } else
+        r = zso_compress_internal(dst, dstCapacity, buf + dictSize, srcSize, level, checksumFlag, dictSize, NULL, 0);
     free(buf);
     return r;
 }
@@ -1432,6 +1530,57 @@ size_t zso_compress_chunked(void* dst, size_t dstCapacity, const void* src, size
         op += c; dstCapacity -= c; ip += n; remaining -= n;
     }
     return (size_t)(op - (u8*)dst);
+}
+
+/* A formatted dictionary for TESTS: magic, dictID, Huffman table, offset / match-length / literal-length NCounts, repcodes
+ * {1,4,8}, content (the layout ZSTD_loadZstdDictionary parses, U/ZstdCompress.cs:5402-5463).  The statistics are those of
+ * the sample's level-1 parse with every symbol counted once more, so that every table covers its whole alphabet — a
+ * stand-in for the reference's trainer (ZDICT_finalizeDictionary, U/Zdict.cs), which is out of scope. */
+size_t zso_make_dictionary(void* dst, size_t cap, const void* content, size_t contentSize,
+                           const void* sample, size_t sampleSize, u32 dictID)
+{
+    u8* const ostart = (u8*)dst; u8* op = ostart; u8* const oend = ostart + cap;
+    u32 litCount[256], ofCount[32], mlCount[64], llCount[64], n, maxSV;
+    zso_seq* seqs; u8* lits; size_t litSize = 0, nbSeq;
+    if (cap < 8 + 512 + 12 + contentSize || contentSize < 8 || sampleSize < 16 || sampleSize > ZSO_BLOCKSIZE_MAX) return ZSO_ERR(GENERIC);
+    seqs = (zso_seq*)malloc((sampleSize / 3 + 2) * sizeof(zso_seq)); lits = (u8*)malloc(sampleSize + 64);
+    if (!seqs || !lits) { free(seqs); free(lits); return ZSO_ERR(memory_allocation); }
+    nbSeq = zso_block_sequences(seqs, sampleSize / 3 + 1, lits, &litSize, sample, sampleSize, 1);
+    for (n = 0; n < 256; n++) litCount[n] = 1;
+    for (n = 0; n < 32; n++) ofCount[n] = 1;
+    for (n = 0; n < 64; n++) { mlCount[n] = 1; llCount[n] = 1; }
+    for (n = 0; n < litSize; n++) litCount[lits[n]]++;
+    for (n = 0; n < nbSeq; n++) {
+        ofCount[zso_highbit32(seqs[n].offBase) & 31]++;
+        mlCount[zso_MLcode(seqs[n].mlBase)]++;
+        llCount[zso_LLcode(seqs[n].litLength)]++;
+    }
+    free(seqs); free(lits);
+    zso_writeLE32(op, 0xEC30A437u); zso_writeLE32(op + 4, dictID); op += 8;
+    {   zso_huf_ct ct; size_t h;
+        size_t const e = huf_buildCTable(&ct, litCount, 255, 11);
+        if (zso_isError(e)) return e;
+        h = huf_writeCTable(op, (size_t)(oend - op), &ct, 255, ct.tableLog);
+        if (zso_isError(h)) return h;
+        op += h;
+    }
+    {   struct { u32* count; u32 max, log; } const t[3] = { { ofCount, 30, 8 }, { mlCount, 52, 9 }, { llCount, 35, 9 } };
+        int k;
+        for (k = 0; k < 3; k++) {
+            s16 norm[64]; size_t total = 0, e, h;
+            for (n = 0; n <= t[k].max; n++) total += t[k].count[n];
+            maxSV = t[k].max;
+            e = zso_fse_normalizeCount(norm, t[k].log, t[k].count, total, maxSV, 0);
+            if (zso_isError(e)) return e;
+            h = zso_fse_writeNCount(op, (size_t)(oend - op), norm, maxSV, t[k].log);
+            if (zso_isError(h)) return h;
+            op += h;
+        }
+    }
+    zso_writeLE32(op, 1); zso_writeLE32(op + 4, 4); zso_writeLE32(op + 8, 8); op += 12;
+    if ((size_t)(oend - op) < contentSize) return ZSO_ERR(dstSize_tooSmall);
+    memcpy(op, content, contentSize); op += contentSize;
+    return (size_t)(op - ostart);
 }
 
 /* ---------- stage hooks ---------- */

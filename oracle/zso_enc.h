@@ -25,10 +25,15 @@ size_t zso_compress(void* dst, size_t dstCapacity, const void* src, size_t srcSi
 size_t zso_compress_chunked(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                             int level, int checksumFlag, size_t chunkSize);
 
-/* Raw-content dictionary as history in front of the input (fast strategy only; see zso_enc.c for what this restates).
+/* Dictionary as history in front of the input — raw content, or formatted (entropy tables and repcodes of its header
+ * become the first block's previous state, ZSTD_loadCEntropy) — fast strategy only; see zso_enc.c for what this restates.
  * Generator of dictionary frames for decoder tests; "parity unpinned". */
 size_t zso_compress_usingDict(void* dst, size_t dstCapacity, const void* src, size_t srcSize,
                               const void* dict, size_t dictSize, int level, int checksumFlag);
+
+/* Writer of a FORMATTED dictionary for tests (see zso_enc.c); zso_compress_usingDict / zso_decompress_usingDict take it. */
+size_t zso_make_dictionary(void* dst, size_t cap, const void* content, size_t contentSize,
+                           const void* sample, size_t sampleSize, u32 dictID);
 
 /* Stage hooks for kernel-level parity tests (SURVEY.md §8 a-4 … a-11). */
 

@@ -31,6 +31,7 @@ def lib():
         o.zso_decompress.restype, o.zso_decompress.argtypes = sz, [vp, sz, vp, sz]
         o.zso_decompress_usingDict.restype, o.zso_decompress_usingDict.argtypes = sz, [vp, sz, vp, sz, vp, sz]
         o.zso_compress_usingDict.restype, o.zso_compress_usingDict.argtypes = sz, [vp, sz, vp, sz, vp, sz, ci, ci]
+        o.zso_make_dictionary.restype, o.zso_make_dictionary.argtypes = sz, [vp, sz, vp, sz, vp, sz, ctypes.c_uint32]
         o.zso_decompressBound.restype, o.zso_decompressBound.argtypes = ctypes.c_uint64, [vp, sz]
         o.zso_findFrameCompressedSize.restype, o.zso_findFrameCompressedSize.argtypes = sz, [vp, sz]
         o.zso_compress.restype, o.zso_compress.argtypes = sz, [vp, sz, vp, sz, ci, ci]
@@ -63,6 +64,15 @@ def decompress(data: bytes, cap: int, dict_bytes: bytes = None):
     else:
         n = lib().zso_decompress(buf, cap, data, len(data))
     return -err_code(n) if is_error(n) else buf.raw[:n]
+
+
+def make_dictionary(content: bytes, sample: bytes, dict_id: int) -> bytes:
+    """a FORMATTED dictionary (magic, dictID, entropy tables from the sample's statistics, repcodes, content): tests only"""
+    cap = len(content) + 2048
+    buf = ctypes.create_string_buffer(cap)
+    n = lib().zso_make_dictionary(buf, cap, content, len(content), sample, len(sample), dict_id)
+    assert not is_error(n), err_code(n)
+    return buf.raw[:n]
 
 
 def compress_dict(data: bytes, dict_bytes: bytes, level: int = 1, checksum: int = 0):

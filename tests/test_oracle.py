@@ -165,3 +165,35 @@ def test_raw_content_dictionary_frames(oracle):
         assert oracle.compress_dict(data, b"1234567", 1, 0) == oracle.compress(data, 1, 0)
     assert oracle.compress_dict(b"x" * 100, bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(60), 1, 0) == -40    # formatted: not restated
     assert oracle.compress_dict(text(5000, 9), dic, 3, 0) == -40                                           # fast strategy only
+
+
+def test_formatted_dictionary_frames(oracle):
+    """Formatted dictionaries (magic, dictID, Huffman + FSE tables, repcodes, content — ZSTD_loadZstdDictionary,
+    U/ZstdCompress.cs:5402-5463; ZSTD_loadDEntropy, U/ZstdDecompress.cs:1773-1875), written by the oracle's test writer.
+    Pinned behaviour: frame header byte 4 carries the dictID size code (0x63-style with a 4-byte id, T/ZstdNetTests.cs:
+    179-212), decoding needs that very dictionary (dictionary_wrong otherwise, :95-134), and the dictionary's tables make
+    tiny inputs smaller than raw content alone does.  Frame bytes: parity unpinned (no dictionary fixtures in the reference)."""
+    import numpy as np
+    r = np.random.default_rng(3)
+    vocab = [bytes(r.integers(97, 123, size=int(r.integers(3, 10))).astype(np.uint8)) for _ in range(200)]
+
+    def text(n, seed):
+        g = np.random.default_rng(seed); out = bytearray()
+        while len(out) < n:
+            out += vocab[int(g.integers(0, len(vocab)))] + b" "
+        return bytes(out[:n])
+
+    content, sample = text(20000, 1), text(60000, 2)
+    dic = oracle.make_dictionary(content, sample, 0x12345678)
+    assert dic[:8] == bytes([0x37, 0xA4, 0x30, 0xEC, 0x78, 0x56, 0x34, 0x12]) and dic.endswith(content)
+    other = oracle.make_dictionary(content, sample, 77)
+    for n in (0, 1, 8, 100, 3000, 70000, 300000):
+        data = text(n, n + 2)
+        frame = oracle.compress_dict(data, dic, 1, 0)
+        assert frame[4] & 3 == 3 and frame[4] & 0x20 and frame[5:9] == dic[4:8]     # single segment, 4-byte dictID right after the FHD
+        assert oracle.decompress(frame, n, dic) == data
+        assert oracle.decompress(frame, n) == -32 and oracle.decompress(frame, n, content) == -32 and oracle.decompress(frame, n, other) == -32
+        if 100 <= n <= 3000:
+            assert len(frame) < len(oracle.compress_dict(data, content, 1, 0)) < len(oracle.compress(data, 1, 0))
+        assert oracle.decompress(oracle.compress(data, 1, 0), n, dic) == data        # dictionary-less frames decode with it loaded
+    assert oracle.decompress(oracle.compress_dict(text(500, 5), dic, 1, 0), 500, dic[:40]) == -30      # truncated header: dictionary_corrupted
