@@ -163,7 +163,7 @@ def test_raw_content_dictionary_frames(oracle):
                 assert oracle.decompress(frame, n) in (-20, -22)                 # corruption_detected / checksum_wrong without it
         assert oracle.decompress(oracle.compress(data, 1, 0), n, dic) == data
         assert oracle.compress_dict(data, b"1234567", 1, 0) == oracle.compress(data, 1, 0)
-    assert oracle.compress_dict(b"x" * 100, bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(60), 1, 0) == -40    # formatted: not restated
+    assert oracle.compress_dict(b"x" * 100, bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(60), 1, 0) == -30    # the magic, then garbage: dictionary_corrupted
     assert oracle.compress_dict(text(5000, 9), dic, 3, 0) == -40                                           # fast strategy only
 
 
