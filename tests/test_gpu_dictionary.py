@@ -181,19 +181,88 @@ def test_null_dictionary_resets_and_tiny_dictionary_is_ignored(gpu_lib, oracle):
         assert oracle.decompress(plain, len(data)) == data
 
 
-def test_formatted_dictionary_is_refused(gpu_lib):
-    """a zstd-format dictionary (magic 0xEC30A437: entropy tables, repcodes, dictID) is out of scope: refused on both sides,
-    never half-applied"""
-    formatted = bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(200)
+def test_formatted_dictionary_compressor_refuses_decompressor_validates(gpu_lib):
+    """The compressor takes raw content only (a formatted dictionary is refused, never half-applied).  The decompressor takes
+    formatted dictionaries and validates their header as ZSTD_loadDEntropy does (U/ZstdDecompress.cs:1773-1875):
+    garbage behind the magic is dictionary_corrupted."""
+    garbage = bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(200)
     with z.Compressor(1) as c, z.Decompressor() as d:
         with pytest.raises(ZstdException) as e:
-            c.LoadDictionary(formatted)
+            c.LoadDictionary(garbage)
         assert e.value.code == 40
         with pytest.raises(ZstdException) as e:
-            d.LoadDictionary(formatted)
-        assert e.value.code == 40
+            d.LoadDictionary(garbage)
+        assert e.value.code == 30
         data = words_text(1000, 1)
         assert d.Unwrap(c.Wrap(data)) == data             # contexts stay usable, without a dictionary
+
+
+def test_formatted_dictionary_frames(gpu_lib, oracle):
+    """Frames made with a FORMATTED dictionary (the kind `DictBuilder.TrainFromBuffer` returns and T/ZstdNetTests.cs uses):
+    first blocks use the dictionary's Huffman table (treeless literals) and FSE tables (repeat mode), repcodes start from the
+    dictionary's, matches reach into its content, the frame header names its dictID (byte 4 = 0x63-style, T:179-212).
+    Dictionary and frames come from the oracle (its test writer and its ZSTD_loadCEntropy restatement)."""
+    content, sample = words_text(20000, 1), words_text(60000, 2)
+    dic = oracle.make_dictionary(content, sample, 0x12345678)
+    other = oracle.make_dictionary(content, sample, 99)
+    with z.Decompressor() as d:
+        d.LoadDictionary(dic)
+        frames, datas = [], []
+        for n in (0, 1, 8, 100, 3000, 40000, 70000, 300000):
+            data = words_text(n, n + 2)
+            for chk in (0, 1):
+                frame = oracle.compress_dict(data, dic, 1, chk)
+                assert frame[4] & 3 == 3 and frame[5:9] == dic[4:8]
+                assert oracle.decompress(frame, n, dic) == data
+                assert d.Unwrap(frame) == data, (n, chk)
+            frames.append(frame); datas.append(data)
+        # many dictionary frames, a dictionary-less one of the oracle and GPU-made frames in one buffer
+        with z.Compressor(1) as c:
+            tail = c.Wrap(datas[-1])
+        blob = b"".join(frames) + oracle.compress(datas[4], 1, 0) + tail
+        assert d.Unwrap(blob) == b"".join(datas) + datas[4] + datas[-1]
+        # the wrong dictionary, raw content only, or none: dictionary_wrong (T/ZstdNetTests.cs:95-134)
+        for wrong in (other, content, None):
+            d.LoadDictionary(wrong)
+            with pytest.raises(ZstdException) as e:
+                d.Unwrap(frames[3])
+            assert e.value.code == 32, wrong is None
+        d.LoadDictionary(dic)
+        assert d.Unwrap(frames[3]) == datas[3]
+
+
+def test_corrupted_formatted_dictionary_frames_fail_cleanly(gpu_lib, oracle):
+    import random
+    rng = random.Random(5)
+    content, sample = words_text(5000, 3), words_text(30000, 4)
+    dic = oracle.make_dictionary(content, sample, 7)
+    seeds = [(oracle.compress_dict(words_text(n, n), dic, 1, chk), n) for n in (200, 4000, 70000) for chk in (0, 1)]
+    errors = 0
+    with z.Decompressor() as d:
+        d.LoadDictionary(dic)
+        for blob, n in seeds:
+            for _ in range(40):
+                b = bytearray(blob)
+                mode = rng.randrange(3)
+                if mode == 0:
+                    i = rng.randrange(len(b)); b[i] ^= 1 << rng.randrange(8)
+                elif mode == 1:
+                    i = rng.randrange(len(b)); b[i] = rng.randrange(256)
+                else:
+                    del b[rng.randrange(4, len(b)):]
+                b = bytes(b)
+                want = oracle.decompress(b, n + 4096, dic)
+                dest = bytearray(n + 4096)
+                try:
+                    got = d.Unwrap(b, dest)
+                    out = bytes(dest[:got])
+                except ZstdException:
+                    out = None
+                if isinstance(want, int):
+                    errors += out is None
+                else:
+                    assert out == want
+    assert errors > 60
 
 
 def test_frame_naming_a_dictionary_id_is_dictionary_wrong(gpu_lib, oracle):

@@ -56,7 +56,8 @@ __device__ inline FrameHeader parse_frame_header(const u8* p, u64 avail)
     return h;
 }
 
-__global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize, FrameDesc* __restrict__ frames, u32 maxFrames, u32* __restrict__ status)
+__global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize, FrameDesc* __restrict__ frames, u32 maxFrames, u32* __restrict__ status,
+                                         u32 dictID)
 {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     u64 pos = 0, dstOff = 0; u32 n = 0, err = 0, nUnsized = 0;
@@ -71,7 +72,7 @@ __global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize
         }
         const FrameHeader h = parse_frame_header(p, avail);
         if (h.err) { err = (h.err == kErrPrefixUnknown && n > 0) ? kErrSrcSizeWrong : h.err; break; }
-        if (h.dictID) { err = kErrDictionaryWrong; break; }
+        if (h.dictID && h.dictID != dictID) { err = kErrDictionaryWrong; break; }       // U/ZstdDecompress.cs:1404-1412 (dictID 0 = none loaded)
         u64 q = pos + h.headerSize; u64 nbBlocks = 0;
         for (;;) {
             if (srcSize - q < 3) { err = kErrSrcSizeWrong; break; }
@@ -519,7 +520,10 @@ __device__ __forceinline__ LitHeader parse_lit_header(const u8* b, u32 bsz)
 }
 
 // literals of every compressed block of one frame -> scratch (one wave; every branch is wave-uniform)
-__device__ u32 decode_frame_literals(LitLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 lane)
+// dictFull / di: a formatted dictionary's bytes and layout (null without one): a treeless block that no block of the frame
+// precedes takes the dictionary's Huffman table (dctx->litEntropy, U/ZstdDecompress.cs:1925-1929).
+__device__ u32 decode_frame_literals(LitLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 lane,
+                                     const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
     u32 ip = h.headerSize, litOff = 0;
@@ -550,7 +554,14 @@ __device__ u32 decode_frame_literals(LitLds& L, const FrameDesc fd, const u8* __
                         if (!hs || hs >= hlen) return kErrCorruption;
                         huf_build_table(L, nbSymbols, tableLog, lane);
                         hsrc += hs; hlen -= hs;
-                    } else if (!uniform(L.hufValid)) return kErrDictionaryCorrupted;
+                    } else if (!uniform(L.hufValid)) {
+                        if (!di) return kErrDictionaryCorrupted;
+                        u32 nbSymbols = 0, tableLog = 0, hs = 0;
+                        if (lane == 0) hs = huf_read_stats(L, dictFull + di->hufOff, di->hufSize, &nbSymbols, &tableLog);
+                        hs = uniform(hs); nbSymbols = uniform(nbSymbols); tableLog = uniform(tableLog);
+                        if (!hs) return kErrDictionaryCorrupted;
+                        huf_build_table(L, nbSymbols, tableLog, lane);
+                    }
                     const u32 tableLog = uniform(L.hufLog);
                     u8* const dst = litOut + litOff;
                     bool ok = true;
@@ -586,15 +597,57 @@ __device__ u32 decode_frame_literals(LitLds& L, const FrameDesc fd, const u8* __
 // slow path: one frame per wave, handles everything (incl. 12-bit Huffman tables); only runs for frames the quad kernel flagged
 __global__ __launch_bounds__(64) void decode_literals_slow_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
                                                                   u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
-                                                                  const u8* __restrict__ slowFlags)
+                                                                  const u8* __restrict__ slowFlags,
+                                                                  const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     __shared__ LitLds L;
     const u32 f = blockIdx.x, lane = threadIdx.x;
-    if (f >= nFrames || !slowFlags[f]) return;
+    if (f >= nFrames || (slowFlags && !slowFlags[f])) return;       // slowFlags null: every frame (formatted dictionary loaded)
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = decode_frame_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, lane);
+    const u32 err = decode_frame_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, lane, dictFull, di);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
+}
+
+// ZSTD_loadDEntropy's checks (U/ZstdDecompress.cs:1773-1875) on one wave: where the Huffman description and the three NCounts
+// sit, the repcodes, where the content starts; err = dictionary_corrupted if anything is off.
+__global__ __launch_bounds__(64) void dict_parse_kernel(const u8* __restrict__ dict, u32 dictSize, DictInfo* __restrict__ out)
+{
+    __shared__ LitLds L;
+    __shared__ s16 norm[64];
+    const u32 lane = threadIdx.x;
+    if (lane != 0) return;
+    DictInfo d = {}; d.err = kErrDictionaryCorrupted;
+    do {
+        if (dictSize <= 8) break;
+        d.dictID = readLE32(dict + 4);
+        u32 nbSymbols = 0, tableLog = 0;
+        const u32 hs = huf_read_stats(L, dict + 8, dictSize - 8, &nbSymbols, &tableLog);
+        if (!hs || tableLog > 12) break;
+        d.hufOff = 8; d.hufSize = hs;
+        u32 p = 8 + hs, maxSV, log, h;
+        maxSV = 31; h = read_ncount(norm, &maxSV, &log, dict + p, dictSize - p);
+        if (!h || maxSV > 31 || log > 8) break;
+        d.ofOff = p; p += h;
+        maxSV = 52; h = read_ncount(norm, &maxSV, &log, dict + p, dictSize - p);
+        if (!h || maxSV > 52 || log > 9) break;
+        d.mlOff = p; p += h;
+        maxSV = 35; h = read_ncount(norm, &maxSV, &log, dict + p, dictSize - p);
+        if (!h || maxSV > 35 || log > 9) break;
+        d.llOff = p; p += h;
+        if (p + 12 > dictSize) break;
+        d.repOff = p;
+        d.contentOff = p + 12; d.contentSize = dictSize - d.contentOff;
+        bool ok = true;
+        for (u32 i = 0; i < 3; i++) { d.rep[i] = readLE32(dict + p + 4 * i); if (d.rep[i] == 0 || d.rep[i] > d.contentSize) ok = false; }
+        if (!ok) break;
+        d.err = 0;
+    } while (false);
+    *out = d;
+}
+void launch_dict_parse(const u8* dict, u32 dictSize, DictInfo* out, hipStream_t stream)
+{
+    hipLaunchKernelGGL(dict_parse_kernel, dim3(1), dim3(64), 0, stream, dict, dictSize, out);
 }
 
 
@@ -1132,7 +1185,8 @@ __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | 
 // round-robin), matches in dependency rounds.
 __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ out,
                                       const u8* __restrict__ litIn, const u32 lane, u32* actualOut,
-                                      const u8* __restrict__ dict, const u32 dictSize)
+                                      const u8* __restrict__ dict, const u32 dictSize,
+                                      const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
 #define FAIL(code) return (code)
 #ifdef ZMI_LZ_STAMPS
@@ -1143,6 +1197,20 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
     u32 rep0 = 1, rep1 = 4, rep2 = 8;
     if (lane == 0) { L.llValid = L.mlValid = L.ofValid = 0; }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    if (di) {
+        // a formatted dictionary: every frame starts from its three FSE tables and its repcodes (dctx->fseEntropy,
+        // ZSTD_decompressBegin_usingDict, U/ZstdDecompress.cs:1956-1990)
+        const u32 ofOff = uniform(di->ofOff), mlOff = uniform(di->mlOff), llOff = uniform(di->llOff), repOff = uniform(di->repOff);
+        u32 r;
+        r = set_seq_table(L, L.ll, &L.llLog, &L.llValid, 2, 35, 9, dictFull + llOff, repOff - llOff, 0, dLL_defaultNorm, 6, 35, lane);
+        if (r == 0xFFFFFFFFu) FAIL(kErrDictionaryCorrupted);
+        r = set_seq_table(L, L.of, &L.ofLog, &L.ofValid, 2, 31, 8, dictFull + ofOff, mlOff - ofOff, 1, dOF_defaultNorm, 5, 28, lane);
+        if (r == 0xFFFFFFFFu) FAIL(kErrDictionaryCorrupted);
+        r = set_seq_table(L, L.ml, &L.mlLog, &L.mlValid, 2, 52, 9, dictFull + mlOff, llOff - mlOff, 2, dML_defaultNorm, 6, 52, lane);
+        if (r == 0xFFFFFFFFu) FAIL(kErrDictionaryCorrupted);
+        rep0 = uniform(di->rep[0]); rep1 = uniform(di->rep[1]); rep2 = uniform(di->rep[2]);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    }
     for (;;) {
         if (fd.srcSize - ip < 3) FAIL(kErrSrcSizeWrong);
         const u32 bh = readLE24(fsrc + ip);
@@ -1422,7 +1490,8 @@ __device__ u32 decode_frame_sequences(SeqLds& L, const FrameDesc fd, const u8* _
 __global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restrict__ src, u64 srcSize, u8* __restrict__ dst, u64 dstCapacity,
                                                               const FrameDesc* __restrict__ frames, u32 nFrames, u32* __restrict__ frameErr,
                                                               const u8* __restrict__ litScratch, u32* __restrict__ frameActual,
-                                                              const u8* __restrict__ dict, u32 dictSize)
+                                                              const u8* __restrict__ dict, u32 dictSize,
+                                                              const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     __shared__ SeqLds L;
     const u32 f = blockIdx.x, lane = threadIdx.x;
@@ -1430,7 +1499,7 @@ __global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restri
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
     u32 actual = 0;
-    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane, &actual, dict, dictSize);
+    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane, &actual, dict, dictSize, dictFull, di);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
     if (frameActual && lane == 0) frameActual[f] = err ? 0u : actual;      // only asked for when some frame carries no content size
 }
@@ -1591,9 +1660,9 @@ void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFra
     hipLaunchKernelGGL(walk_link_kernel, dim3(1), dim3(1024), 0, stream, segs, nSeg, srcSize, maxFrames, frameBase, dstBase, status);
     hipLaunchKernelGGL(walk_emit_kernel, dim3((nSeg + 255) / 256), dim3(256), 0, stream, src, srcSize, segs, nSeg, frameBase, dstBase, status, frames);
 }
-void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream)
+void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, u32 dictID, hipStream_t stream)
 {
-    hipLaunchKernelGGL(frame_walk_serial_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status);
+    hipLaunchKernelGGL(frame_walk_serial_kernel, dim3(1), dim3(64), 0, stream, src, srcSize, frames, maxFrames, status, dictID);
 }
 // =====================================================================================================================
 // Literal decoder, self-synchronising form (rows a-15, a-16): one 256-thread workgroup per frame, wave w decodes Huffman
@@ -1933,8 +2002,13 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
 //   selfsync (256 lanes per frame): 0.15 ms up to 256 frames, 0.25 ms per 1000 frames beyond.
 // mode: 0 = choose by frame count, 1 = serial, 2 = self-synchronising, 3 = compact.
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
-                            u8* slowFlags, u32 mode, hipStream_t stream)
+                            u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream)
 {
+    if (di) {       // a formatted dictionary is loaded: treeless first blocks take its Huffman table, which only the wave-per-frame form knows
+        hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity,
+                           (const u8*)nullptr, dictFull, di);
+        return;
+    }
     if (mode == 0) {
         static int cus[64] = {};                     // per device
         int dev = 0; (void)hipGetDevice(&dev);
@@ -1956,14 +2030,16 @@ void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames,
     }
     if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
     else           hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
-    hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
+    hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity,
+                       (const u8*)slowFlags, (const u8*)nullptr, (const DictInfo*)nullptr);
 }
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, hipStream_t stream)
+                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, const u8* dictFull, const DictInfo* di,
+                             hipStream_t stream)
 {
     // dict: a raw-content dictionary = history in front of EVERY frame (ZSTD_refDictContent, U/ZstdDecompress.cs:1758-1771); may be null
     hipLaunchKernelGGL(decode_sequences_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, dst, dstCapacity, frames, nFrames, frameErr, litScratch,
-                       frameActual, dict, dict ? dictSize : 0u);
+                       frameActual, dict, dict ? dictSize : 0u, dictFull, di);
 }
 
 #ifdef ZMI_LZ_STAMPS

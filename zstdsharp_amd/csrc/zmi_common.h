@@ -56,6 +56,19 @@ struct HufTable {
 };
 
 // ---- decoder side ----
+// A formatted dictionary as the decoder sees it (filled by dict_parse_kernel; ZSTD_loadDEntropy, U/ZstdDecompress.cs:1773-1875):
+// offsets into the dictionary bytes of the Huffman description and of the three NCounts, the repcodes, where the content starts.
+struct DictInfo {
+    u32 err;                        // 0, or kErrDictionaryCorrupted
+    u32 dictID;
+    u32 hufOff, hufSize;
+    u32 ofOff, mlOff, llOff;        // each NCount runs up to the next offset (llOff up to repOff)
+    u32 repOff;
+    u32 rep[3];
+    u32 contentOff, contentSize;
+    u32 pad[3];
+};
+
 struct FrameDesc {      // one per frame found by the frame walk (U/ZstdDecompress.cs:877-951)
     u64 srcOff;         // offset of the frame in the compressed input
     u64 dstOff;         // offset of its content in the output

@@ -29,11 +29,13 @@ void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 
 size_t decode_walk_workspace_bytes(u64 srcSize);
 void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total [4]=usable*/,
                        u8* walkWs, hipStream_t stream);
-void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, hipStream_t stream);
+void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, u32 dictID, hipStream_t stream);
+void launch_dict_parse(const u8* dict, u32 dictSize, DictInfo* out, hipStream_t stream);
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
-                            u8* slowFlags, u32 mode, hipStream_t stream);
+                            u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream);
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, hipStream_t stream);
+                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, const u8* dictFull, const DictInfo* di,
+                             hipStream_t stream);
 }
 
 using namespace zmi;
@@ -133,8 +135,10 @@ struct ZSTD_DCtx_s {
     // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
     std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
     u32 litDecoder = 0;         // 0 auto, 1 serial (4 lanes per frame), 2 self-synchronising (256 lanes per frame), 3 serial with compact tables
-    // raw-content dictionary (ZSTD_DCtx_loadDictionary): host copy, uploaded at the next decompression
-    std::vector<u8> dictHost; DevBuf dict; bool dictDirty = false;
+    // dictionary (ZSTD_DCtx_loadDictionary): host copy, uploaded at the next decompression.  Raw content: the bytes are the
+    // history.  Formatted (magic 0xEC30A437): dict_parse_kernel validates the header and fills `info`; the history is the content.
+    std::vector<u8> dictHost; DevBuf dict, dictInfoDev; bool dictDirty = false, dictFormatted = false;
+    DictInfo info = {};
 };
 
 
@@ -150,6 +154,7 @@ static size_t cctx_bind(ZSTD_CCtx* c)
     } else if (hipSetDevice(c->device) != hipSuccess) return ZERR(kErrInitMissing);
     return 0;
 }
+static size_t dctx_sync_dictionary(ZSTD_DCtx* d);
 static size_t dctx_bind(ZSTD_DCtx* d)
 {
     if (!d) return ZERR(kErrGeneric);
@@ -385,7 +390,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->actual.release(); d->dict.release();
+        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->actual.release(); d->dict.release(); d->dictInfoDev.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -404,9 +409,9 @@ size_t ZSTD_DCtx_getParameter(ZSTD_DCtx* d, int param, int* value)
     if (param == ZSTD_d_windowLogMax) { *value = d->windowLogMax; return 0; }
     return ZERR(kErrParameterUnsupported);
 }
-// Raw-content dictionaries only (ZSTD_decompress_insertDictionary's "no magic" branch -> ZSTD_refDictContent,
-// U/ZstdDecompress.cs:1909-1931, 1758-1771): the bytes become history in front of every frame.  A formatted dictionary
-// (magic 0xEC30A437: entropy tables + repcodes + dictID) is refused, never half-applied.
+// ZSTD_decompress_insertDictionary, U/ZstdDecompress.cs:1909-1931: without the magic the bytes are raw content, history in
+// front of every frame (ZSTD_refDictContent, :1758-1771); with it (0xEC30A437) the header's Huffman and FSE tables and
+// repcodes are what every frame starts from and frames must name its dictID or none (ZSTD_loadDEntropy, :1773-1875).
 size_t ZSTD_DCtx_loadDictionary(ZSTD_DCtx* d, const void* dict, size_t dictSize)
 {
     if (!d) return ZERR(kErrGeneric);
@@ -416,8 +421,10 @@ size_t ZSTD_DCtx_loadDictionary(ZSTD_DCtx* d, const void* dict, size_t dictSize)
     if (is_device_ptr(dict)) {
         if (hipMemcpy(h.data(), dict, dictSize, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
     } else memcpy(h.data(), dict, dictSize);
-    if (is_formatted_dictionary(h.data(), dictSize)) return ZERR(kErrParameterUnsupported);
+    d->dictFormatted = is_formatted_dictionary(h.data(), dictSize);
     d->dictHost.swap(h);
+    d->dictDirty = true;
+    if (d->dictFormatted && !isErr(dctx_bind(d))) return dctx_sync_dictionary(d);      // validated now when a device is there, else at first use
     d->dictDirty = true;
     return 0;
 }
@@ -513,6 +520,25 @@ unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
     }
 }
 
+// upload a newly loaded dictionary; a formatted one is validated on the device (ZSTD_loadDEntropy's checks) -> dictionary_corrupted
+static size_t dctx_sync_dictionary(ZSTD_DCtx* d)
+{
+    if (!d->dictDirty) return 0;
+    hipStream_t s = d->stream;
+    if (!d->dictHost.empty()) {
+        if (!d->dict.ensure(d->dictHost.size() + 64) || !d->dictInfoDev.ensure(sizeof(DictInfo))) return ZERR(kErrMemoryAllocation);
+        if (hipMemcpyAsync(d->dict.p, d->dictHost.data(), d->dictHost.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (d->dictFormatted) {
+            launch_dict_parse((const u8*)d->dict.p, (u32)d->dictHost.size(), (DictInfo*)d->dictInfoDev.p, s);
+            if (hipMemcpyAsync(&d->info, d->dictInfoDev.p, sizeof(DictInfo), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        }
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        if (d->dictFormatted && d->info.err) { d->dictHost.clear(); d->dictFormatted = false; d->dictDirty = false; return ZERR(kErrDictionaryCorrupted); }
+    }
+    d->dictDirty = false;
+    return 0;
+}
+
 static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
 {
     hipStream_t s = d->stream;
@@ -522,6 +548,13 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     if (!d->frames.ensure((size_t)maxFrames * sizeof(FrameDesc)) || !d->status.ensure(64) || !d->walkWs.ensure(decode_walk_workspace_bytes(srcSize)))
         return ZERR(kErrMemoryAllocation);
     FrameDesc* frames = (FrameDesc*)d->frames.p; u32* status = (u32*)d->status.p;
+    { const size_t e = dctx_sync_dictionary(d); if (isErr(e)) return e; }
+    const bool fmt = d->dictFormatted && !d->dictHost.empty();
+    const u8* const dictFull = fmt ? (const u8*)d->dict.p : nullptr;
+    const DictInfo* const dinfo = fmt ? (const DictInfo*)d->dictInfoDev.p : nullptr;
+    const u8* const dictContent = d->dictHost.empty() ? nullptr : (const u8*)d->dict.p + (fmt ? d->info.contentOff : 0u);
+    const u32 dictContentSize = d->dictHost.empty() ? 0u : (fmt ? d->info.contentSize : (u32)d->dictHost.size());
+    const u32 dictID = fmt ? d->info.dictID : 0u;
     d->timer.begin(s);
     launch_frame_walk(d_src, srcSize, frames, maxFrames, status, (u8*)d->walkWs.p, s);       d->timer.mark("frame_walk", s);
     u32 st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -529,7 +562,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     const bool serialWalk = !st[4];
     if (serialWalk) {   // the segment links did not close: take the exact serial walk (it also yields the reference's error code)
-        launch_frame_walk_serial(d_src, srcSize, frames, maxFrames, status, s);
+        launch_frame_walk_serial(d_src, srcSize, frames, maxFrames, status, dictID, s);
         if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
         if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     }
@@ -540,21 +573,13 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     if (nFrames == 0) { d->timer.finish(); return 0; }
     if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
     (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
-    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, d->litDecoder, s);     d->timer.mark("decode_literals", s);
+    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s);     d->timer.mark("decode_literals", s);
     // frames without a content size (st[5] of them; only the serial walk lets them through) are decoded into bound-sized
     // slots, report their regenerated size, and are then moved down to close the gaps
     const u32 nUnsized = serialWalk ? st[5] : 0u;
     if (nUnsized && !d->actual.ensure((size_t)nFrames * sizeof(u32))) return ZERR(kErrMemoryAllocation);
-    if (d->dictDirty) {
-        if (!d->dictHost.empty()) {
-            if (!d->dict.ensure(d->dictHost.size() + 64)) return ZERR(kErrMemoryAllocation);
-            if (hipMemcpyAsync(d->dict.p, d->dictHost.data(), d->dictHost.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
-            if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-        }
-        d->dictDirty = false;
-    }
     launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, nUnsized ? (u32*)d->actual.p : nullptr,
-                            d->dictHost.empty() ? nullptr : (const u8*)d->dict.p, (u32)d->dictHost.size(), s);   d->timer.mark("decode_sequences", s);
+                            dictContent, dictContentSize, dictFull, dinfo, s);   d->timer.mark("decode_sequences", s);
     u32 err = 0;
     if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
