@@ -43,9 +43,12 @@ size_t     ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                   /* 
 size_t     ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, int param, int value);
 size_t     ZSTD_CCtx_getParameter(const ZSTD_CCtx* cctx, int param, int* value);
 /* S/Compressor.cs:43-56 (dictionary load) -> U/ZstdCompress.cs:1286-1330, 5465-5503.  RAW-CONTENT dictionaries (any bytes
- * that do not start with the magic 0xEC30A437): history in front of every frame, no dictID.  NULL/0 = no dictionary;
- * under 8 bytes = ignored, as in the reference; a formatted (trained) dictionary -> parameter_unsupported.  The pointer
- * may be host or device memory; the bytes are copied. */
+ * that do not start with the magic 0xEC30A437): history in front of every frame, no dictID.  FORMATTED dictionaries (the
+ * magic, a dictID, entropy tables, repcodes, content — what the trainer returns): the content is the history, the frames
+ * carry the dictID (unless ZSTD_c_dictIDFlag = 0) and start from the dictionary's repcodes; its entropy tables are not
+ * used (every block carries its own — valid for any decoder holding the dictionary).  A malformed header ->
+ * dictionary_corrupted (at this call when a device is bound, else at first use).  NULL/0 = no dictionary; under 8 bytes =
+ * ignored, as in the reference.  The pointer may be host or device memory; the bytes are copied. */
 size_t     ZSTD_CCtx_loadDictionary(ZSTD_CCtx* cctx, const void* dict, size_t dictSize);
 /* S/Compressor.cs:73-76 -> U/ZstdCompress.cs:19-22 */
 size_t     ZSTD_compressBound(size_t srcSize);
@@ -63,7 +66,9 @@ ZSTD_DCtx* ZSTD_createDCtx(void);
 size_t     ZSTD_freeDCtx(ZSTD_DCtx* dctx);
 size_t     ZSTD_DCtx_setParameter(ZSTD_DCtx* dctx, int param, int value);   /* S/Decompressor.cs:41-46 */
 size_t     ZSTD_DCtx_getParameter(ZSTD_DCtx* dctx, int param, int* value);
-/* S/Decompressor.cs:36-48 -> U/ZstdDecompress.cs:1909-1931, 1758-1771: raw-content dictionaries, as above */
+/* S/Decompressor.cs:36-48 -> U/ZstdDecompress.cs:1909-1931, 1758-1875: raw-content dictionaries (history in front of every
+ * frame) and formatted ones (frames start from the dictionary's Huffman/FSE tables and repcodes and must name its dictID or
+ * none; a malformed header -> dictionary_corrupted) */
 size_t     ZSTD_DCtx_loadDictionary(ZSTD_DCtx* dctx, const void* dict, size_t dictSize);
 /* S/Decompressor.cs:53 -> U/ZstdDecompress.cs:971-993 ; error = (unsigned long long)-2 (S/ThrowHelper.cs:7-8) */
 unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize);

@@ -68,9 +68,11 @@ def test_parameters_without_a_device():
     assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_unsupported
     c.LoadDictionary(b"some dictionary bytes")             # raw content: kept on the host until a compression needs it
     c.LoadDictionary(None)
-    with pytest.raises(ZstdException) as e:
-        c.LoadDictionary(bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(64))      # formatted (trained) dictionaries are out of scope
-    assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_unsupported
+    c.LoadDictionary(bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(64))          # formatted: its header is validated on the device, i.e. at
+    with pytest.raises(ZstdException) as e:                                # first use when none is there yet — and there is none here
+        c.Wrap(b"x" * 100)
+    assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_init_missing
+    c.LoadDictionary(None)
     c.Dispose()
     with pytest.raises(RuntimeError):
         c.Wrap(b"x")

@@ -181,20 +181,55 @@ def test_null_dictionary_resets_and_tiny_dictionary_is_ignored(gpu_lib, oracle):
         assert oracle.decompress(plain, len(data)) == data
 
 
-def test_formatted_dictionary_compressor_refuses_decompressor_validates(gpu_lib):
-    """The compressor takes raw content only (a formatted dictionary is refused, never half-applied).  The decompressor takes
-    formatted dictionaries and validates their header as ZSTD_loadDEntropy does (U/ZstdDecompress.cs:1773-1875):
-    garbage behind the magic is dictionary_corrupted."""
+def test_formatted_dictionary_header_is_validated(gpu_lib):
+    """Both contexts validate a formatted dictionary's header as ZSTD_loadDEntropy / ZSTD_loadCEntropy do
+    (U/ZstdDecompress.cs:1773-1875, U/ZstdCompress.cs:5259-5400): garbage behind the magic is dictionary_corrupted."""
     garbage = bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(200)
     with z.Compressor(1) as c, z.Decompressor() as d:
         with pytest.raises(ZstdException) as e:
             c.LoadDictionary(garbage)
-        assert e.value.code == 40
+        assert e.value.code == 30
         with pytest.raises(ZstdException) as e:
             d.LoadDictionary(garbage)
         assert e.value.code == 30
         data = words_text(1000, 1)
         assert d.Unwrap(c.Wrap(data)) == data             # contexts stay usable, without a dictionary
+
+
+@pytest.mark.parametrize("level", [1, 3, 5])
+def test_compress_with_formatted_dictionary(gpu_lib, oracle, level):
+    """T/ZstdNetTests.cs:19-39, 148-164, 179-212 with a formatted dictionary: round trip under the oracle's dictionary decoder
+    and the GPU's; the header carries the dictID (byte 4 & 3 = size code, then the id, then the content size); the dictionary
+    helps; without it or with another one the frames are refused.  (The compressor uses the dictionary's content, dictID and
+    repcodes; its entropy tables are left unused — every block carries its own.)"""
+    content, sample = words_text(20000, 1), words_text(60000, 2)
+    for dict_id, code in ((0x12345678, 3), (300, 2), (7, 1)):
+        dic = oracle.make_dictionary(content, sample, dict_id)
+        with z.Compressor(level) as c, z.Decompressor() as d:
+            c.LoadDictionary(dic); d.LoadDictionary(dic)
+            for n in (0, 1, 100, 3000, 40000, 70000, 300001):
+                data = words_text(n, n + 9)
+                comp = c.Wrap(data)
+                if n:
+                    assert comp[4] & 3 == code and int.from_bytes(comp[5:5 + (4 if code == 3 else code)], "little") == dict_id
+                    assert comp[4] & 0x20                                       # single segment: the content size follows the dictID
+                assert oracle.decompress(comp, n, dic) == data, (level, n)
+                assert d.Unwrap(comp) == data, (level, n)
+            small = words_text(3000, 5)
+            with z.Compressor(level) as plain:
+                assert len(c.Wrap(small)) < len(plain.Wrap(small))
+            comp = c.Wrap(small)
+            for wrong in (oracle.make_dictionary(content, sample, dict_id + 1), content, None):
+                d.LoadDictionary(wrong)
+                with pytest.raises(ZstdException) as e:
+                    d.Unwrap(comp)
+                assert e.value.code == 32
+            # ZSTD_c_dictIDFlag = 0: no dictID in the header; the holder of the dictionary still decodes
+            c.SetParameter(202, 0)
+            comp = c.Wrap(small)
+            assert comp[4] & 3 == 0
+            d.LoadDictionary(dic)
+            assert d.Unwrap(comp) == small and oracle.decompress(comp, len(small), dic) == small
 
 
 def test_formatted_dictionary_frames(gpu_lib, oracle):

@@ -158,7 +158,8 @@ template <int MODE, int SHORT, bool DICT>
 __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
-                                                  const u8* __restrict__ prefix, const u32 prefixLen, const u32 chunkBytes)
+                                                  const u8* __restrict__ prefix, const u32 prefixLen, const u32 chunkBytes,
+                                                  const u32 fhExtra)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -695,7 +696,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #endif
     if (tid == 0) {
         ChunkMeta m = {};
-        m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(nData);
+        m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(nData) + fhExtra;      // fhExtra: bytes of the dictID field (formatted dictionary), else 0
         meta[c] = m;
     }
 }
@@ -712,7 +713,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, hipStream_t stream)
 {
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
@@ -721,7 +722,7 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -729,20 +730,20 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // prefix/prefixLen: the dictionary bytes every chunk sees as history (null/0 without one); chunkBytes = 64 KiB minus prefixLen
 // rounded up to whole 4 KiB tiles.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, hipStream_t stream)
 {
     if (prefixLen == 0 || chunkBytes >= kChunkSize) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, stream); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, stream); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, stream); break;
     }
 }
 

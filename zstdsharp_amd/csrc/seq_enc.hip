@@ -160,7 +160,8 @@ __device__ __forceinline__ u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count
 }
 
 __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs, ChunkMeta* __restrict__ meta,
-                                                         u8* __restrict__ slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps)
+                                                         u8* __restrict__ slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
+                                                         u32 dictID, u32 dictIdBytes, u32 initRep0, u32 initRep1, u32 initRep2)
 {
     __shared__ SeqWaveLds Ws[4];
     const u32 lane = lane_id(), wave = wave_id();
@@ -186,7 +187,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
         //   rep1 before k  = rep0 before j, j = the latest earlier sequence that was not a plain rep0 hit;
         //   rep2 before k  = rep1 before j, j = the latest earlier sequence that neither hit rep0 nor swapped with rep1.
         // "Latest earlier sequence with a property" is a ballot and a count-leading-zeros; the value comes by shuffle.
-        u32 R0 = 1, R1 = 4, R2 = 8;                    // history before the batch (uniform)
+        u32 R0 = initRep0, R1 = initRep1, R2 = initRep2;      // history before the batch (uniform): {1,4,8}, or a formatted dictionary's repcodes
         for (u32 b0 = 0; b0 < nbSeq; b0 += 64) {
             const u32 i = b0 + lane;
             Seq s; s.offBase = 4; s.litLength = 0; s.mlBase = 0;
@@ -368,10 +369,13 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     {
         const u32 fcsCode = (n >= 256) + (n >= 65536 + 256);
         writeLE32(slot, 0xFD2FB528u);
-        slot[4] = (u8)(((checksumFlag ? 1u : 0u) << 2) + (1u << 5) + (fcsCode << 6));
-        if (fcsCode == 0) slot[5] = (u8)n;
-        else if (fcsCode == 1) writeLE16(slot + 5, n - 256);
-        else writeLE32(slot + 5, n);
+        const u32 didCode = dictIdBytes == 4 ? 3u : dictIdBytes;          // dictID field of 0, 1, 2 or 4 bytes (U/ZstdCompress.cs:4843-4849, 4896-4918)
+        slot[4] = (u8)(didCode + ((checksumFlag ? 1u : 0u) << 2) + (1u << 5) + (fcsCode << 6));
+        for (u32 i = 0; i < dictIdBytes; i++) slot[5 + i] = (u8)(dictID >> (8 * i));
+        u8* const fcs = slot + 5 + dictIdBytes;
+        if (fcsCode == 0) fcs[0] = (u8)n;
+        else if (fcsCode == 1) writeLE16(fcs, n - 256);
+        else writeLE32(fcs, n);
     }
     u8* const bh = slot + m.fhSize;
     if (giveUp) {            // ZSTD_noCompressBlock: the gather kernel copies the n source bytes behind this header
@@ -385,9 +389,11 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     meta[c] = m;
 }
 
-void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream)
+void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
+                       u32 dictID, u32 dictIdBytes, const u32* initReps, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag, resolveReps);
+    hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag, resolveReps,
+                       dictID, dictIdBytes, initReps[0], initReps[1], initReps[2]);
 }
 
 #ifdef ZMI_LZ_STAMPS

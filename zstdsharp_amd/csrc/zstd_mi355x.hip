@@ -16,11 +16,12 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, hipStream_t stream);
-void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps, hipStream_t stream);
+void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
+                       u32 dictID, u32 dictIdBytes, const u32* initReps, hipStream_t stream);
 void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
 void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
                    u32 nChunks, u32 chunkBytes, hipStream_t stream);
@@ -109,8 +110,12 @@ struct ZSTD_CCtx_s {
     std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
     StageTimer timer;
     float stageMs[kMaxStages] = {}; const char* stageNames[kMaxStages] = {}; int nStages = 0;
-    // raw-content dictionary (ZSTD_CCtx_loadDictionary): the last kDictKeep bytes, host copy + device copy made at the next compression
-    std::vector<u8> dictHost; DevBuf dict; bool dictDirty = false;
+    // dictionary (ZSTD_CCtx_loadDictionary).  dictHost = the history bytes: the last kDictKeep bytes of a raw-content dictionary
+    // or of a formatted dictionary's content; host copy + device copy made at the next compression.  A formatted dictionary
+    // (dictFull, validated on the device into `info`) also gives the frames their dictID and the first repcodes; its entropy
+    // tables are not used (every block carries its own), which any decoder holding the dictionary accepts.
+    std::vector<u8> dictHost, dictFull; DevBuf dict, dictFullDev, dictInfoDev; bool dictDirty = false, dictFormatted = false;
+    DictInfo info = {};
 };
 // History per chunk lives in LDS beside the chunk: up to 32 KiB of dictionary in front of 32 KiB chunks, or up to 60 KiB when
 // the whole input fits behind it in one chunk (small records, the usual dictionary case).
@@ -142,6 +147,7 @@ struct ZSTD_DCtx_s {
 };
 
 
+static size_t cctx_sync_dictionary(ZSTD_CCtx* c);
 static size_t cctx_bind(ZSTD_CCtx* c)
 {
     if (!c) return ZERR(kErrGeneric);
@@ -183,6 +189,32 @@ static u32 strategy_for_level(int level) { (void)level; return 1; }
 // 3-4 doubleFast -> the dual-hash finder, >= 5 greedy/lazy -> dual-hash + lazy deferral.  See lz_fast.hip.
 static u32 finder_for_level(int level) { return level <= 2 ? 0u : level <= 4 ? 1u : 2u; }
 
+// upload a newly loaded dictionary; a formatted one is first validated on the device (ZSTD_loadCEntropy's checks are those of
+// ZSTD_loadDEntropy plus the symbol-coverage rules that only matter to an encoder reusing the tables) -> dictionary_corrupted
+static size_t cctx_sync_dictionary(ZSTD_CCtx* c)
+{
+    if (!c->dictDirty) return 0;
+    hipStream_t s = c->stream;
+    if (c->dictFormatted) {
+        const size_t n = c->dictFull.size();
+        if (!c->dictFullDev.ensure(n + 64) || !c->dictInfoDev.ensure(sizeof(DictInfo))) return ZERR(kErrMemoryAllocation);
+        if (hipMemcpyAsync(c->dictFullDev.p, c->dictFull.data(), n, hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+        launch_dict_parse((const u8*)c->dictFullDev.p, (u32)n, (DictInfo*)c->dictInfoDev.p, s);
+        if (hipMemcpyAsync(&c->info, c->dictInfoDev.p, sizeof(DictInfo), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        if (c->info.err) { c->dictFull.clear(); c->dictHost.clear(); c->dictFormatted = false; c->dictDirty = false; return ZERR(kErrDictionaryCorrupted); }
+        const size_t keep = c->info.contentSize < kDictKeep ? c->info.contentSize : kDictKeep;
+        c->dictHost.assign(c->dictFull.end() - (ptrdiff_t)keep, c->dictFull.end());
+    }
+    if (!c->dictHost.empty()) {
+        if (!c->dict.ensure(c->dictHost.size() + 64)) return ZERR(kErrMemoryAllocation);
+        if (hipMemcpyAsync(c->dict.p, c->dictHost.data(), c->dictHost.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    }
+    c->dictDirty = false;
+    return 0;
+}
+
 // the compress pipeline over device-resident buffers
 static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
 {
@@ -198,16 +230,14 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         (void)hipStreamSynchronize(s);
         return n;
     }
+    { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
     const u32 prefixLen = dict_prefix_len(c, srcSize);
     const u32 chunkBytes = kChunkSize - round_tile(prefixLen);
-    if (c->dictDirty) {
-        if (!c->dictHost.empty()) {
-            if (!c->dict.ensure(c->dictHost.size() + 64)) return ZERR(kErrMemoryAllocation);
-            if (hipMemcpyAsync(c->dict.p, c->dictHost.data(), c->dictHost.size(), hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
-            if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-        }
-        c->dictDirty = false;
-    }
+    // a formatted dictionary: its dictID in every frame header (unless ZSTD_c_dictIDFlag = 0), its repcodes in front of every frame
+    const u32 dictID = c->dictFormatted ? c->info.dictID : 0u;
+    const u32 dictIdBytes = (dictID && c->dictIDFlag) ? (dictID < 256 ? 1u : dictID < 65536 ? 2u : 4u) : 0u;
+    const u32 plainReps[3] = { 1, 4, 8 };
+    const u32* const initReps = c->dictFormatted ? c->info.rep : plainReps;
     const u8* prefix = prefixLen ? (const u8*)c->dict.p + (c->dictHost.size() - prefixLen) : nullptr;
     const u64 totalChunks = (srcSize + chunkBytes - 1) / chunkBytes;
     const u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
@@ -222,10 +252,10 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, s);                      c->timer.mark("lz_fast", s);
+        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, s);                      c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, s);                        c->timer.mark("huf_build", s);
         if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             c->timer.mark("xxh64", s); }
-        launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, s);   c->timer.mark("seq_encode", s);
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, s);   c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
@@ -257,7 +287,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
         (void)hipSetDevice(c->device);
         if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
         c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release();
-        c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release();
+        c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release(); c->dictFullDev.release(); c->dictInfoDev.release();
         c->timer.destroy();
         if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     }
@@ -310,23 +340,34 @@ size_t ZSTD_CCtx_getParameter(const ZSTD_CCtx* c, int param, int* value)
     }
 }
 
-// Raw-content dictionaries only (ZSTD_compress_insertDictionary's dct_auto branch without the magic ->
-// ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5465-5503, 5126-5237); the frames carry no dictID (there is none), exactly as
-// the reference writes them.  A formatted dictionary (magic 0xEC30A437) is refused.
+// ZSTD_compress_insertDictionary, U/ZstdCompress.cs:5465-5503: without the magic the bytes are raw content
+// (ZSTD_loadDictionaryContent, :5126-5237) and the frames carry no dictID, exactly as the reference writes them; with it, a
+// formatted dictionary (ZSTD_loadZstdDictionary, :5402-5463).
 size_t ZSTD_CCtx_loadDictionary(ZSTD_CCtx* c, const void* dict, size_t dictSize)
 {
     if (!c) return ZERR(kErrGeneric);
     if (!c->sIn.empty() || c->sEnding) return ZERR(kErrStageWrong);        /* not in the middle of a streaming frame session, U/ZstdCompress.cs:1273 */
+    c->dictFormatted = false; c->dictFull.clear();
     if (dict == nullptr || dictSize == 0) { c->dictHost.clear(); c->dictDirty = true; return 0; }          /* "no dictionary" */
+    if (dictSize > (size_t)1 << 30) return ZERR(kErrParameterUnsupported);
+    u8 head[8] = {};
+    const bool dev = is_device_ptr(dict);
+    if (dev) { if (hipMemcpy(head, dict, dictSize < 8 ? dictSize : 8, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric); }
+    else memcpy(head, dict, dictSize < 8 ? dictSize : 8);
+    if (is_formatted_dictionary(head, dictSize)) {
+        // ZSTD_loadZstdDictionary, U/ZstdCompress.cs:5402-5463: dictID + repcodes + content are used (see ZSTD_CCtx_s::dictHost)
+        std::vector<u8> full(dictSize);
+        if (dev) { if (hipMemcpy(full.data(), dict, dictSize, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric); }
+        else memcpy(full.data(), dict, dictSize);
+        c->dictFull.swap(full); c->dictHost.clear(); c->dictFormatted = true; c->dictDirty = true;
+        if (!isErr(cctx_bind(c))) return cctx_sync_dictionary(c);          // validated now when a device is there, else at first use
+        return 0;
+    }
     const size_t keep = dictSize < kDictKeep ? dictSize : kDictKeep;
     std::vector<u8> h(dictSize < 8 ? dictSize : keep);
     const u8* tail = (const u8*)dict + (dictSize - h.size());
-    u8 head[8] = {};
-    if (is_device_ptr(dict)) {
-        if (hipMemcpy(h.data(), tail, h.size(), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
-        if (hipMemcpy(head, dict, dictSize < 8 ? dictSize : 8, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
-    } else { memcpy(h.data(), tail, h.size()); memcpy(head, dict, dictSize < 8 ? dictSize : 8); }
-    if (is_formatted_dictionary(head, dictSize)) return ZERR(kErrParameterUnsupported);
+    if (dev) { if (hipMemcpy(h.data(), tail, h.size(), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric); }
+    else memcpy(h.data(), tail, h.size());
     c->dictHost.swap(h);
     c->dictDirty = true;
     return 0;
@@ -830,7 +871,8 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
     launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
     launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, s);
-    launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, strategy_for_level(c->level), 0, 0, s);
+    { const u32 plainReps[3] = { 1, 4, 8 };
+      launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, strategy_for_level(c->level), 0, 0, 0, 0, plainReps, s); }
     if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     if (m.blockType != 2) return 0;
