@@ -399,3 +399,22 @@ def test_frames_without_content_size_with_dictionary(gpu_lib, oracle):
         dest = bytearray(gpu_lib.ZSTD_decompressBound(blob, len(blob)))
         got = d.Unwrap(blob, dest)
         assert bytes(dest[:got]) == b"".join(parts)
+
+
+def test_streaming_with_formatted_dictionary(gpu_lib, oracle):
+    """S/CompressionStream.cs:58-62, S/DecompressionStream.cs:58-62 with a formatted dictionary; the decompression stream is
+    also fed frames made by the oracle with the dictionary's entropy tables in use"""
+    content, sample = words_text(12000, 21), words_text(50000, 22)
+    dic = oracle.make_dictionary(content, sample, 4242)
+    data = words_text(150000, 23)
+    tmp = io.BytesIO()
+    with CompressionStream(tmp) as cs:
+        cs.LoadDictionary(dic)
+        cs.Write(data[:1000]); cs.Flush(); cs.Write(data[1000:])
+    blob = tmp.getvalue()
+    assert oracle.decompress(blob, len(data), dic) == data
+    pieces = [words_text(m, m + 30) for m in (50, 900, 30000)]
+    blob += b"".join(oracle.compress_dict(p, dic, 1, 1) for p in pieces)
+    with DecompressionStream(io.BytesIO(blob), 777) as ds:
+        ds.LoadDictionary(dic)
+        assert ds.ReadToEnd(5000) == data + b"".join(pieces)
