@@ -418,3 +418,24 @@ def test_streaming_with_formatted_dictionary(gpu_lib, oracle):
     with DecompressionStream(io.BytesIO(blob), 777) as ds:
         ds.LoadDictionary(dic)
         assert ds.ReadToEnd(5000) == data + b"".join(pieces)
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3])
+def test_formatted_dictionary_frames_on_every_literal_decoder(gpu_lib, oracle, mode):
+    """a treeless first literals block takes the dictionary's Huffman table in each of the literal decoders"""
+    content, sample = words_text(9000, 31), words_text(40000, 32)
+    dic = oracle.make_dictionary(content, sample, 1000 + mode)
+    with z.Decompressor() as d:
+        assert gpu_lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, mode) == 0
+        d.LoadDictionary(dic)
+        parts, blob, treeless = [], b"", 0
+        for n in (70, 300, 1000, 5000, 40000, 140000):
+            for k in range(3):
+                data = words_text(n, 7 * n + k)
+                frame = oracle.compress_dict(data, dic, 1, k & 1)
+                fh = 5 + (0, 1, 2, 4)[frame[4] & 3] + (1 if n < 256 else 2 if n < 65536 + 256 else 4)
+                treeless += (frame[fh + 3] & 3) == 3                      # first block's literals section: Treeless_Literals_Block
+                parts.append(data); blob += frame
+                assert d.Unwrap(frame) == data, (mode, n, k)
+        assert treeless >= 6                                               # the dictionary's table really is in use
+        assert d.Unwrap(blob) == b"".join(parts)

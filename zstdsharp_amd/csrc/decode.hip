@@ -736,7 +736,8 @@ __device__ __forceinline__ bool huf_decode_stream4(const u16* __restrict__ table
 // One frame on the 4 lanes of a quad.  Header parsing is done redundantly by the 4 lanes (same loads, same values, so
 // the quad's control flow is uniform without any cross-lane traffic); only the weight decoding runs on the quad leader.
 // Returns an error code, or 0xFFFF to ask for the slow path (12-bit table).
-__device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 ql)
+__device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 ql,
+                                    const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
     u32 ip = h.headerSize, litOff = 0;
@@ -759,13 +760,15 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
                 if (lh.type >= 2) {
                     if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
                     const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
-                    if (lh.type == 2) {
+                    const bool fromDict = lh.type == 3 && !haveTable && di != nullptr;      // a treeless first block takes the dictionary's table
+                    const u8* const tsrc = fromDict ? dictFull + di->hufOff : hsrc; const u32 tlen = fromDict ? di->hufSize : hlen;
+                    if (lh.type == 2 || fromDict) {
                         if (ql == 0) {
                             QuadScratch sc;
                             sc.weights = Q.weights; sc.norm = reinterpret_cast<s16*>(Q.huf); sc.symbolNext = Q.huf + 256;
                             sc.wNewState = Q.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(Q.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(Q.huf + 608);
                             u32 nbSymbols = 0, tl = 0;
-                            const u32 hs = huf_read_stats(sc, hsrc, hlen, &nbSymbols, &tl);
+                            const u32 hs = huf_read_stats(sc, tsrc, tlen, &nbSymbols, &tl);
                             if (hs && tl <= 11) {          // rank starts -> per-symbol first index (HUF_readDTableX1)
                                 u32 cnt[13]; for (int i = 0; i < 13; i++) cnt[i] = 0;
                                 for (u32 n = 0; n < nbSymbols; n++) cnt[Q.weights[n]]++;
@@ -777,7 +780,7 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                         const u32 hs = Q.meta[0], nbSymbols = Q.meta[1]; tableLog = Q.meta[2];
-                        if (!hs || hs >= hlen) return kErrCorruption;
+                        if (!hs || (fromDict ? hs > tlen : hs >= hlen)) return fromDict ? kErrDictionaryCorrupted : kErrCorruption;
                         if (tableLog > 11) return 0xFFFFu;
                         for (u32 n = ql; n < nbSymbols; n += 4) {          // table fill, 4 lanes
                             const u32 w = Q.weights[n];
@@ -789,7 +792,7 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                         haveTable = true;
-                        hsrc += hs; hlen -= hs;
+                        if (!fromDict) { hsrc += hs; hlen -= hs; }
                     } else if (!haveTable) return kErrDictionaryCorrupted;
                     u8* const dst = litOut + litOff;
                     bool ok = true;
@@ -909,7 +912,8 @@ __device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ tabl
 }
 
 // One frame on the 4 lanes of a quad (compact tables).  Returns an error code, or 0xFFFF to ask for the slow path.
-__device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 ql)
+__device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 ql,
+                                      const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
     u32 ip = h.headerSize, litOff = 0;
@@ -932,14 +936,16 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                 if (lh.type >= 2) {
                     if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
                     const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
-                    if (lh.type == 2) {
+                    const bool fromDict = lh.type == 3 && !haveTable && di != nullptr;      // a treeless first block takes the dictionary's table
+                    const u8* const tsrc = fromDict ? dictFull + di->hufOff : hsrc; const u32 tlen = fromDict ? di->hufSize : hlen;
+                    if (lh.type == 2 || fromDict) {
                         u8* const weights = reinterpret_cast<u8*>(Q.huf + 896);     // top 256 B of the table area until the fill
                         if (ql == 0) {
                             QuadScratch sc;
                             sc.weights = weights; sc.norm = reinterpret_cast<s16*>(Q.huf); sc.symbolNext = Q.huf + 256;
                             sc.wNewState = Q.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(Q.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(Q.huf + 608);
                             u32 nbSymbols = 0, tl = 0;
-                            const u32 hs = huf_read_stats(sc, hsrc, hlen, &nbSymbols, &tl);
+                            const u32 hs = huf_read_stats(sc, tsrc, tlen, &nbSymbols, &tl);
                             if (hs && tl <= 11) {          // class extents (HUF_readDTableX1) and the symbols in (weight, symbol) order
                                 for (u32 w = 0; w < 14; w++) { Q.classStart[w] = 0; Q.classFirst[w] = 0; }
                                 for (u32 n = 0; n < nbSymbols; n++) Q.classFirst[weights[n]]++;             // counts, for now
@@ -958,7 +964,7 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                         const u32 hs = Q.meta[0]; tableLog = Q.meta[2];
-                        if (!hs || hs >= hlen) return kErrCorruption;
+                        if (!hs || (fromDict ? hs > tlen : hs >= hlen)) return fromDict ? kErrDictionaryCorrupted : kErrCorruption;
                         if (tableLog > 11) return 0xFFFFu;
                         {   // table fill by the quad's 4 lanes, one symbol of `sorted` at a time
                             const u32 nSorted = Q.classFirst[tableLog + 1];
@@ -981,7 +987,7 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
                         haveTable = true;
                         n1 = tableLog > 10 ? Q.classFirst[2] : 0u;
-                        hsrc += hs; hlen -= hs;
+                        if (!fromDict) { hsrc += hs; hlen -= hs; }
                     } else if (!haveTable) return kErrDictionaryCorrupted;
                     u8* const dst = litOut + litOff;
                     bool ok = true;
@@ -1016,7 +1022,8 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const FrameDesc fd, const u
 
 __global__ __launch_bounds__(64) void decode_literals_compact_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
                                                                      u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
-                                                                     u8* __restrict__ slowFlags)
+                                                                     u8* __restrict__ slowFlags,
+                                                                     const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     __shared__ CompactLds Qs[kQuads];
     const u32 lane = threadIdx.x, q = lane >> 2, ql = lane & 3;
@@ -1025,7 +1032,7 @@ __global__ __launch_bounds__(64) void decode_literals_compact_kernel(const u8* _
     const FrameDesc fd = frames[f];
     if (ql == 0) slowFlags[f] = 0;
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (ql == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = quad_decode_literals_c(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql);
+    const u32 err = quad_decode_literals_c(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql, dictFull, di);
     if (ql == 0) {
         if (err == 0xFFFFu) slowFlags[f] = 1;
         else if (err) atomicCAS(frameErr, 0u, err);
@@ -1034,7 +1041,8 @@ __global__ __launch_bounds__(64) void decode_literals_compact_kernel(const u8* _
 
 __global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
                                                              u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
-                                                             u8* __restrict__ slowFlags)
+                                                             u8* __restrict__ slowFlags,
+                                                             const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     __shared__ QuadLds Qs[kQuads];
     const u32 lane = threadIdx.x, q = lane >> 2, ql = lane & 3;
@@ -1043,7 +1051,7 @@ __global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restric
     const FrameDesc fd = frames[f];
     if (ql == 0) slowFlags[f] = 0;
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (ql == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = quad_decode_literals(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql);
+    const u32 err = quad_decode_literals(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql, dictFull, di);
     if (ql == 0) {
         if (err == 0xFFFFu) slowFlags[f] = 1;
         else if (err) atomicCAS(frameErr, 0u, err);
@@ -1879,7 +1887,8 @@ __device__ __forceinline__ bool huf_decode_stream_sync(const u16* __restrict__ t
     return huf_stream_passes<false>(table, tableLog, src, srcSize, last, out, n, lane);
 }
 
-__device__ __forceinline__ u32 sync_decode_literals(SyncLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 tid)
+__device__ __forceinline__ u32 sync_decode_literals(SyncLds& L, const FrameDesc fd, const u8* __restrict__ fsrc, u8* __restrict__ litOut, const u32 tid,
+                                                    const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     const u32 lane = tid & 63, wave = tid >> 6;
     const FrameHeader h = parse_frame_header(fsrc, fd.srcSize);
@@ -1903,19 +1912,21 @@ __device__ __forceinline__ u32 sync_decode_literals(SyncLds& L, const FrameDesc 
                 if (lh.type >= 2) {
                     if (lh.litSize > fd.dstSize - litOff) return kErrCorruption;
                     const u8* hsrc = b + lh.lhSize; u32 hlen = lh.litCSize;
-                    if (lh.type == 2) {
+                    const bool fromDict = lh.type == 3 && !haveTable && di != nullptr;      // a treeless first block takes the dictionary's table
+                    const u8* const tsrc = fromDict ? dictFull + di->hufOff : hsrc; const u32 tlen = fromDict ? di->hufSize : hlen;
+                    if (lh.type == 2 || fromDict) {
                         __syncthreads();                               // the previous block's streams are done with the table
                         if (tid == 0) {
                             QuadScratch sc;
                             sc.weights = L.weights; sc.norm = reinterpret_cast<s16*>(L.huf); sc.symbolNext = L.huf + 256;
                             sc.wNewState = L.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(L.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(L.huf + 608);
                             u32 nbSymbols = 0, tl = 0;
-                            const u32 hs = huf_read_stats(sc, hsrc, hlen, &nbSymbols, &tl);
+                            const u32 hs = huf_read_stats(sc, tsrc, tlen, &nbSymbols, &tl);
                             L.meta[0] = hs; L.meta[1] = nbSymbols; L.meta[2] = tl; L.err = 0;
                         }
                         __syncthreads();
                         const u32 hs = L.meta[0], nbSymbols = L.meta[1]; tableLog = L.meta[2];
-                        if (!hs || hs >= hlen) return kErrCorruption;
+                        if (!hs || (fromDict ? hs > tlen : hs >= hlen)) return fromDict ? kErrDictionaryCorrupted : kErrCorruption;
                         if (tableLog > 12) return kErrTableLogTooLarge;
                         if (wave == 0) {       // HUF_readDTableX1_wksp (U/HufDecompress.cs:80-251): symbols by (weight, symbol), class extents
                             u32 wk[4], pos[4];
@@ -1950,7 +1961,7 @@ __device__ __forceinline__ u32 sync_decode_literals(SyncLds& L, const FrameDesc 
                         }
                         __syncthreads();
                         haveTable = true;
-                        hsrc += hs; hlen -= hs;
+                        if (!fromDict) { hsrc += hs; hlen -= hs; }
                     } else if (!haveTable) return kErrDictionaryCorrupted;
                     u8* const dst = litOut + litOff;
                     bool ok = true;
@@ -1982,7 +1993,8 @@ __device__ __forceinline__ u32 sync_decode_literals(SyncLds& L, const FrameDesc 
 }
 
 __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __restrict__ src, u64 srcSize, const FrameDesc* __restrict__ frames,
-                                                                   u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity)
+                                                                   u32 nFrames, u32* __restrict__ frameErr, u8* __restrict__ litScratch, u64 dstCapacity,
+                                                                   const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     extern __shared__ __attribute__((aligned(16))) u8 syncLdsRaw[];
     SyncLds& L = *reinterpret_cast<SyncLds*>(syncLdsRaw);
@@ -1992,7 +2004,7 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
     if (tid == 0) L.err = 0;
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (tid == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
     __syncthreads();
-    const u32 err = sync_decode_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, tid);
+    const u32 err = sync_decode_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, tid, dictFull, di);
     if (err && tid == 0) atomicCAS(frameErr, 0u, err);
 }
 
@@ -2004,11 +2016,6 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
 void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
                             u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream)
 {
-    if (di) {       // a formatted dictionary is loaded: treeless first blocks take its Huffman table, which only the wave-per-frame form knows
-        hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity,
-                           (const u8*)nullptr, dictFull, di);
-        return;
-    }
     if (mode == 0) {
         static int cus[64] = {};                     // per device
         int dev = 0; (void)hipGetDevice(&dev);
@@ -2025,13 +2032,13 @@ void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames,
         static bool attrSet[64] = {};               // per device
         int dev = 0; (void)hipGetDevice(&dev);
         if (!attrSet[dev & 63]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_literals_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SyncLds)); attrSet[dev & 63] = true; }
-        hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nFrames), dim3(256), sizeof(SyncLds), stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity);
+        hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nFrames), dim3(256), sizeof(SyncLds), stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, dictFull, di);
         return;
     }
-    if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
-    else           hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags);
+    if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags, dictFull, di);
+    else           hipLaunchKernelGGL(decode_literals_kernel, dim3((nFrames + kQuads - 1) / kQuads), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity, slowFlags, dictFull, di);
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nFrames), dim3(64), 0, stream, src, srcSize, frames, nFrames, frameErr, litScratch, dstCapacity,
-                       (const u8*)slowFlags, (const u8*)nullptr, (const DictInfo*)nullptr);
+                       (const u8*)slowFlags, dictFull, di);
 }
 void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
                              const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, const u8* dictFull, const DictInfo* di,
