@@ -24,6 +24,9 @@ namespace zmi {
 // ------------------------------------------------------------------------------------------------
 // frame walk
 // ------------------------------------------------------------------------------------------------
+// Literal scratch of frame f starts at its output offset + f * kLitSkew: without the skew all frames' streams write addresses
+// that agree in their low 14 bits at any moment (four 16 KiB segments per 64 KiB frame, decoded in lockstep).
+constexpr u32 kLitSkew = 320;
 struct FrameHeader { u64 contentSize; u64 windowSize; u32 headerSize; u32 checksum; u32 dictID; u32 err; };
 
 __device__ inline FrameHeader parse_frame_header(const u8* p, u64 avail)
@@ -605,7 +608,7 @@ __global__ __launch_bounds__(64) void decode_literals_slow_kernel(const u8* __re
     if (f >= nFrames || (slowFlags && !slowFlags[f])) return;       // slowFlags null: every frame (formatted dictionary loaded)
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = decode_frame_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, lane, dictFull, di);
+    const u32 err = decode_frame_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff + (u64)f * kLitSkew, lane, dictFull, di);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
 }
 
@@ -836,8 +839,8 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const FrameDesc fd, const u8* __
 struct CompactLds {
     u16 huf[1024];              // byte | nbBits << 8; the first n1/2 entries (owned by pairs of 11-bit codes): symbol(bit 0) | symbol(bit 1) << 8.  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
     u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded; its head = the 11-bit codes in table order
-    u32 classStart[14];         // first index (in the tableLog-bit table) of weight class w; [tableLog + 1] = table size
-    u32 classFirst[14];         // index into sorted[] of the first symbol of class w
+    u16 classStart[14];         // first index (in the tableLog-bit table) of weight class w; [tableLog + 1] = table size
+    u16 classFirst[14];         // index into sorted[] of the first symbol of class w
     u32 meta[4];
 };
 
@@ -1032,7 +1035,7 @@ __global__ __launch_bounds__(64) void decode_literals_compact_kernel(const u8* _
     const FrameDesc fd = frames[f];
     if (ql == 0) slowFlags[f] = 0;
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (ql == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = quad_decode_literals_c(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql, dictFull, di);
+    const u32 err = quad_decode_literals_c(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff + (u64)f * kLitSkew, ql, dictFull, di);
     if (ql == 0) {
         if (err == 0xFFFFu) slowFlags[f] = 1;
         else if (err) atomicCAS(frameErr, 0u, err);
@@ -1051,7 +1054,7 @@ __global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restric
     const FrameDesc fd = frames[f];
     if (ql == 0) slowFlags[f] = 0;
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (ql == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
-    const u32 err = quad_decode_literals(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff, ql, dictFull, di);
+    const u32 err = quad_decode_literals(Qs[q], fd, src + fd.srcOff, litScratch + fd.dstOff + (u64)f * kLitSkew, ql, dictFull, di);
     if (ql == 0) {
         if (err == 0xFFFFu) slowFlags[f] = 1;
         else if (err) atomicCAS(frameErr, 0u, err);
@@ -1507,7 +1510,7 @@ __global__ __launch_bounds__(64) void decode_sequences_kernel(const u8* __restri
     const FrameDesc fd = frames[f];
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (lane == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
     u32 actual = 0;
-    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff, lane, &actual, dict, dictSize, dictFull, di);
+    const u32 err = decode_frame_sequences(L, fd, src + fd.srcOff, dst + fd.dstOff, litScratch + fd.dstOff + (u64)f * kLitSkew, lane, &actual, dict, dictSize, dictFull, di);
     if (err && lane == 0) atomicCAS(frameErr, 0u, err);
     if (frameActual && lane == 0) frameActual[f] = err ? 0u : actual;      // only asked for when some frame carries no content size
 }
@@ -2004,7 +2007,7 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
     if (tid == 0) L.err = 0;
     if (fd.srcOff + fd.srcSize > srcSize || fd.dstOff + fd.dstSize > dstCapacity) { if (tid == 0) atomicCAS(frameErr, 0u, (u32)kErrGeneric); return; }
     __syncthreads();
-    const u32 err = sync_decode_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff, tid, dictFull, di);
+    const u32 err = sync_decode_literals(L, fd, src + fd.srcOff, litScratch + fd.dstOff + (u64)f * kLitSkew, tid, dictFull, di);
     if (err && tid == 0) atomicCAS(frameErr, 0u, err);
 }
 
