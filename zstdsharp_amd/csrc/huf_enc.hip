@@ -277,7 +277,7 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const u32 litSize = meta[c].litSize, nbSeqIn = meta[c].nbSeq;
     HufWork* __restrict__ W = reinterpret_cast<HufWork*>(slots + (u64)c * kSlotStride);
-    const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
+    const u8* __restrict__ lit = lits + (u64)c * kLitStride;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
@@ -590,7 +590,7 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const ChunkMeta m = meta[c];
     const u32 litSize = m.litSize;
-    const u8* __restrict__ lit = lits + ((u64)c << kChunkLog);
+    const u8* __restrict__ lit = lits + (u64)c * kLitStride;
     u8* __restrict__ body = slots + (u64)c * kSlotStride + m.fhSize + 3;      // block body starts after frame + block header
     if (dst) {
         if (m.blockType != 2) return;                                        // stored raw: gather copies the source bytes

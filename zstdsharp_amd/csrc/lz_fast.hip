@@ -217,7 +217,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     ZMI_STAMP(0);
 
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
-    u8* __restrict__ litOut = lits + ((u64)c << kChunkLog);
+    u8* __restrict__ litOut = lits + (u64)c * kLitStride;
     // parse state, kept identically in every thread's registers (all updates come from LDS values read after a barrier)
     u32 cursor = hist;   // absolute position where the parse of the previous tiles ended (= end of the last selected match)
     u32 nbSeq = 0, litBase = 0;

@@ -18,6 +18,9 @@ typedef int32_t  s32;
 // ---- framing: one independent zstd frame per 64 KiB chunk ----
 constexpr u32 kChunkLog   = 16;
 constexpr u32 kChunkSize  = 1u << kChunkLog;
+// literal buffer of chunk c starts at c * kLitStride: the 320-byte skew keeps the chunks' writers and readers, which move in
+// lockstep, from hitting addresses that agree in their low 16 bits (channel camping)
+constexpr u32 kLitStride  = kChunkSize + 320;
 constexpr u32 kSlotStride = kChunkSize + 512;      // >= ZSTD_compressBound(64 KiB) + frame/block headers + checksum
 constexpr u32 kMaxSeq     = kChunkSize / 4;        // a sequence consumes >= 4 input bytes in this match finder
 

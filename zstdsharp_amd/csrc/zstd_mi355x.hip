@@ -176,7 +176,7 @@ static size_t dctx_bind(ZSTD_DCtx* d)
 
 static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
 {
-    return c->seqs.ensure((size_t)nChunks * kMaxSeq * sizeof(Seq)) && c->lits.ensure((size_t)nChunks * kChunkSize + 64) &&
+    return c->seqs.ensure((size_t)nChunks * kMaxSeq * sizeof(Seq)) && c->lits.ensure((size_t)nChunks * kLitStride + 64) &&
            c->meta.ensure((size_t)nChunks * sizeof(ChunkMeta)) && c->tables.ensure((size_t)nChunks * sizeof(HufTable)) &&
            c->slots.ensure((size_t)nChunks * kSlotStride + 64) && c->offsets.ensure((size_t)nChunks * sizeof(u64)) &&
            c->total.ensure(64);
@@ -853,7 +853,7 @@ size_t ZSTDMI_debugGetChunk(ZSTD_CCtx* c, size_t chunkIdx, ZSTDMI_Seq* seqs, siz
     *nbSeq = m.nbSeq; *litSize = m.litSize;
     const size_t ns = m.nbSeq < seqCap ? m.nbSeq : seqCap, nl = m.litSize < litCap ? m.litSize : litCap;
     if (ns && hipMemcpy(seqs, (Seq*)c->seqs.p + chunkIdx * kMaxSeq, ns * sizeof(Seq), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
-    if (nl && hipMemcpy(lits, (u8*)c->lits.p + chunkIdx * kChunkSize, nl, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    if (nl && hipMemcpy(lits, (u8*)c->lits.p + chunkIdx * kLitStride, nl, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
     return 0;
 }
 
