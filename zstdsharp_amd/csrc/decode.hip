@@ -24,9 +24,6 @@ namespace zmi {
 // ------------------------------------------------------------------------------------------------
 // frame walk
 // ------------------------------------------------------------------------------------------------
-// Literal scratch of frame f starts at its output offset + f * kLitSkew: without the skew all frames' streams write addresses
-// that agree in their low 14 bits at any moment (four 16 KiB segments per 64 KiB frame, decoded in lockstep).
-constexpr u32 kLitSkew = 320;
 struct FrameHeader { u64 contentSize; u64 windowSize; u32 headerSize; u32 checksum; u32 dictID; u32 err; };
 
 __device__ inline FrameHeader parse_frame_header(const u8* p, u64 avail)

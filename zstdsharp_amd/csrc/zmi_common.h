@@ -59,6 +59,13 @@ struct HufTable {
 };
 
 // ---- decoder side ----
+// Literal scratch of frame f starts at its output offset + f * kLitSkew: without the skew all frames' streams write addresses
+// that agree in their low 14 bits at any moment (four 16 KiB segments per 64 KiB frame, decoded in lockstep).
+#ifndef ZMI_LITSKEW
+#define ZMI_LITSKEW 320
+#endif
+constexpr u32 kLitSkew = ZMI_LITSKEW;
+
 // A formatted dictionary as the decoder sees it (filled by dict_parse_kernel; ZSTD_loadDEntropy, U/ZstdDecompress.cs:1773-1875):
 // offsets into the dictionary bytes of the Huffman description and of the three NCounts, the repcodes, where the content starts.
 struct DictInfo {

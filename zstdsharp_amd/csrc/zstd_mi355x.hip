@@ -612,7 +612,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     const u64 total = (u64)st[2] | ((u64)st[3] << 32);
     if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
     if (nFrames == 0) { d->timer.finish(); return 0; }
-    if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + (size_t)nFrames * 320 + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
+    if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + (size_t)nFrames * kLitSkew + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
     (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
     launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s);     d->timer.mark("decode_literals", s);
     // frames without a content size (st[5] of them; only the serial walk lets them through) are decoded into bound-sized
