@@ -281,25 +281,31 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // acceleration (ZSTD_fast's step = 1 + ((ip - anchor) >> kSearchStrength), U/ZstdFast.cs:130-136).  A match that starts
     // between probed positions is still picked up one or two bytes later and grown backward at emission.
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
+    u32 prevStride = 0;                  // the previous iteration's stride
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
     for (u32 t = 0, it = 0; t < nTiles; ++it) {
         const u32 tileStart = t * kTilePos;
-        const u32 strideLog = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);     // uniform
         const bool histTile = DICT && tileStart < hist;                                         // uniform: dictionary bytes, insert only
-        // Super-tile: where only every 2nd / 4th position is probed, TWO / FOUR tiles (as many as are left in full) are taken
-        // in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies overlap and the
-        // two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot (slot order = position
-        // order), coverage has up to 256 words, and the selection is the serial walk of wave 0 whatever the number of
-        // matches (capped; what is left out stays literals).
-        u32 nSubT = 1u << strideLog;
+        // stride: every 2nd / 4th position after a sparse tile; where a strided iteration found next to nothing either, every
+        // 8th, then every 16th (the reference's step keeps growing the same way while nothing matches, U/ZstdFast.cs:130-136)
+        u32 strideSel = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);            // uniform
+        if (prevDensity < 4 && prevStride >= 2) strideSel = prevStride < 4 ? prevStride + 1 : 4u;
+        // Super-tile: where only every 2nd / 4th (8th, 16th) position is probed, TWO / FOUR tiles (as many as are left in
+        // full) are taken in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies
+        // overlap and the two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot
+        // (slot order = position order), coverage has up to 256 words, and the selection is the serial walk of wave 0
+        // whatever the number of matches (capped; what is left out stays literals).
+        u32 nSubT = strideSel > 2 ? 4u : 1u << strideSel;          // at most 16 KiB per iteration: the stride adapts again after that
         { const u32 fullLeft = (n - tileStart) >> kTileLog; if (nSubT > fullLeft) nSubT = fullLeft; }
         const bool super = nSubT >= 2 && !histTile;                                     // uniform
-        if (!super) nSubT = 1;
+        if (!super) { nSubT = 1; if (strideSel > 2) strideSel = 2; }                    // (a lone tile knows strides 1, 2, 4 only)
+        const u32 strideLog = strideSel;
         span = nSubT << kTileLog;
+        const u32 slots = span >> strideLog;                                            // probes of this iteration (<= 4096)
         // first-occurrence entries: base + tile-relative position, 16 bits, smaller for later tiles (atomicMin keeps the
         // current tile's earliest).  Tile t owns [(15-t) << 12, +4096); a super-tile owns the ranges of the tiles it covers.
         const u32 stamp = ((kChunkSize / kTilePos) - t - nSubT) << kTileLog;
-        const u32 nPass = (kPPT >> strideLog) * nSubT, par = it % 3;
+        const u32 nPass = (slots + kTile - 1) / kTile, par = it % 3;
         covPar = it & 1;
         cov = super ? superCov : L.covMask[covPar];
         // (A sparse tile could fuse probe and verify and defer its table inserts behind the verify barrier — one barrier
@@ -322,7 +328,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = probed(j), p = tileStart + q;
-            valid[j] = j < nPass && p + 8 <= n && p >= lowLimit; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
+            valid[j] = j < nPass && j * kTile + tid < slots && p + 8 <= n && p >= lowLimit; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
             if (j >= nPass) continue;            // uniform
             if (valid[j]) {
                 w[j] = lds_load8(L.in, p);
@@ -478,6 +484,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         }
         // matches per 4096 positions had every position been probed
         prevDensity = histTile ? 0xFFFFFFFFu : (matchCount << strideLog) / nSubT;     // history and the tile after it: every position
+        prevStride = histTile ? 0u : strideLog;
         const bool any = matchCount != 0 && c0 < span;                   // uniform
         const bool dense = any && matchCount > 64 && !super;
         if (dense) {
@@ -634,11 +641,11 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(6);
         const u32 nSel = any ? L.wordRank[64] : 0u;
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
-        const u32 nSub = span >> kTileLog;          // 1, or 4 in a super-tile: the compaction below runs per 4096 positions
-        const u32 q16 = tid * 16;                   // sixteen positions per thread: a tile takes 256 threads, a super-tile up to 1024
+        const u32 nSub = span >> kTileLog;          // 1, or up to 16 in a super-tile: the compaction below runs per 4096 positions
+        // sixteen positions per thread: a tile takes 256 threads, four sub-tiles of a super-tile all 1024 (one pass per four)
         if (!any && c0 == 0 && tileStart + span <= n) {
             // nothing selected, nothing carried in, full tile: every byte is a literal, copied straight through
-            if (q16 < span) {
+            for (u32 q16 = tid * 16; q16 < span; q16 += kTile * 16) {
                 const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
                 u32u* o = (u32u*)(litOut + litBase + q16);
                 o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
@@ -648,7 +655,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             const u32 lastEnd = nSel ? endOf[nSel] : cursor;
             // Every wave scans the group words itself (one LDS read per lane and sub-tile), so the compaction offsets need
             // neither a cross-wave table nor another barrier.  keepG(sub, g) = bytes of group g of sub-tile `sub` that are
-            // literals.  The (up to four) sub-tiles of a super-tile are scanned side by side.
+            // literals.  Four sub-tiles of a super-tile are scanned side by side.
             auto keepG = [&](u32 sub, u32 g) -> u64 {
                 const u32 g0 = sub * kTilePos + g * 64;             // tile-relative
                 u64 k = ~cov[sub * kGroups + g];
@@ -657,35 +664,38 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 if (c0 > g0) k = (c0 - g0 >= 64) ? 0ull : (k & (~0ull << (c0 - g0)));      // before the entry cursor: inside an earlier match
                 return k;
             };
-            u32 gcnt[4], gincl[4];
+            for (u32 s0 = 0; s0 < nSub; s0 += 4) {           // uniform
+                u32 gcnt[4], gincl[4];
 #pragma unroll
-            for (u32 sub = 0; sub < 4; ++sub) gcnt[sub] = sub < nSub ? popc64(keepG(sub, lane)) : 0u;       // (uniform predicate)
+                for (u32 k = 0; k < 4; ++k) gcnt[k] = s0 + k < nSub ? popc64(keepG(s0 + k, lane)) : 0u;       // (uniform predicate)
 #pragma unroll
-            for (u32 sub = 0; sub < 4; ++sub) gincl[sub] = sub < nSub ? wave_scan_incl(gcnt[sub]) : 0u;
-            const u32 tot0 = read_lane(gincl[0], 63), tot1 = read_lane(gincl[1], 63), tot2 = read_lane(gincl[2], 63), tot3 = read_lane(gincl[3], 63);
-            if (q16 < span) {                                // whole waves: 256 threads per sub-tile
-                const u32 mySub = tid >> 8, gl = (tid >> 2) & 63u, sh = (tid & 3u) * 16u;
-                const u32 myExcl = mySub == 0 ? gincl[0] - gcnt[0] : mySub == 1 ? gincl[1] - gcnt[1] : mySub == 2 ? gincl[2] - gcnt[2] : gincl[3] - gcnt[3];
-                const u32 subBase = mySub == 0 ? 0u : mySub == 1 ? tot0 : mySub == 2 ? tot0 + tot1 : tot0 + tot1 + tot2;
-                const u32 gexcl = __shfl(myExcl, (int)gl);
-                const u64 kgw = keepG(mySub, gl);
-                const u32 keep16 = (u32)(kgw >> sh) & 0xFFFFu;
-                if (keep16) {
-                    u8* o = litOut + litBase + subBase + gexcl + popc64(kgw & ((1ull << sh) - 1));
-                    const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
-                    if (keep16 == 0xFFFFu) { u32u* o4 = (u32u*)o; o4[0] = v.x; o4[1] = v.y; o4[2] = v.z; o4[3] = v.w; }
-                    else {
-                        const u32 d[4] = { v.x, v.y, v.z, v.w };
+                for (u32 k = 0; k < 4; ++k) gincl[k] = s0 + k < nSub ? wave_scan_incl(gcnt[k]) : 0u;
+                const u32 tot0 = read_lane(gincl[0], 63), tot1 = read_lane(gincl[1], 63), tot2 = read_lane(gincl[2], 63), tot3 = read_lane(gincl[3], 63);
+                const u32 q16 = s0 * kTilePos + tid * 16;
+                if (q16 < span) {                            // whole waves: 256 threads per sub-tile
+                    const u32 kSub = tid >> 8, gl = (tid >> 2) & 63u, sh = (tid & 3u) * 16u;
+                    const u32 myExcl = kSub == 0 ? gincl[0] - gcnt[0] : kSub == 1 ? gincl[1] - gcnt[1] : kSub == 2 ? gincl[2] - gcnt[2] : gincl[3] - gcnt[3];
+                    const u32 subBase = kSub == 0 ? 0u : kSub == 1 ? tot0 : kSub == 2 ? tot0 + tot1 : tot0 + tot1 + tot2;
+                    const u32 gexcl = __shfl(myExcl, (int)gl);
+                    const u64 kgw = keepG(s0 + kSub, gl);
+                    const u32 keep16 = (u32)(kgw >> sh) & 0xFFFFu;
+                    if (keep16) {
+                        u8* o = litOut + litBase + subBase + gexcl + popc64(kgw & ((1ull << sh) - 1));
+                        const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
+                        if (keep16 == 0xFFFFu) { u32u* o4 = (u32u*)o; o4[0] = v.x; o4[1] = v.y; o4[2] = v.z; o4[3] = v.w; }
+                        else {
+                            const u32 d[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
-                        for (u32 k = 0; k < 4; ++k) {
-                            const u32 keep = (keep16 >> (4 * k)) & 0xFu, w4 = d[k];
-                            if (keep == 0xFu) { *(u32u*)o = w4; o += 4; }
-                            else { if (keep & 1) *o++ = (u8)w4; if (keep & 2) *o++ = (u8)(w4 >> 8); if (keep & 4) *o++ = (u8)(w4 >> 16); if (keep & 8) *o++ = (u8)(w4 >> 24); }
+                            for (u32 k = 0; k < 4; ++k) {
+                                const u32 keep = (keep16 >> (4 * k)) & 0xFu, w4 = d[k];
+                                if (keep == 0xFu) { *(u32u*)o = w4; o += 4; }
+                                else { if (keep & 1) *o++ = (u8)w4; if (keep & 2) *o++ = (u8)(w4 >> 8); if (keep & 4) *o++ = (u8)(w4 >> 16); if (keep & 8) *o++ = (u8)(w4 >> 24); }
+                            }
                         }
                     }
                 }
+                litBase += tot0 + tot1 + tot2 + tot3;
             }
-            litBase += tot0 + tot1 + tot2 + tot3;
             nbSeq += nSel; cursor = lastEnd;
         }
         t += nSub;
