@@ -290,6 +290,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // 8th, then every 16th (the reference's step keeps growing the same way while nothing matches, U/ZstdFast.cs:130-136)
         u32 strideSel = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);            // uniform
         if (prevDensity < 4 && prevStride >= 2) strideSel = prevStride < 4 ? prevStride + 1 : 4u;
+        else if (prevDensity == 0 && !histTile && t != 0) strideSel = 3;                // nothing at all in the previous tile(s), whatever their stride
         // Super-tile: where only every 2nd / 4th (8th, 16th) position is probed, TWO / FOUR tiles (as many as are left in
         // full) are taken in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies
         // overlap and the two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot
