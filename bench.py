@@ -126,9 +126,13 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1")); rank = int(os.environ.get("RANK", "0")); local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus > 1 and world == 1:
         print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run (one rank per GPU)", file=sys.stderr); sys.exit(2)
-    assert lib.ZSTDMI_deviceCount() > local, "no MI355X visible: the product has no CPU fallback"
+    # torch touches the GPU first: its wheel bundles its own HIP runtime, which cannot enumerate the device once the system
+    # runtime behind libzstd_mi355x.so holds it (the other order works; tests/conftest.py does the same)
+    assert torch.cuda.is_available(), "no MI355X visible: the product has no CPU fallback"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.zeros(1, device=dev)
+    assert lib.ZSTDMI_deviceCount() > local, "no MI355X visible to the library: the product has no CPU fallback"
     dist = None
     if world > 1:
         import torch.distributed as dist

@@ -39,7 +39,11 @@ enum {
 /* ---- compression context: S/Compressor.cs:32,60,138 -> U/ZstdCompress.cs:24-27, 43-62, 137-160 ---- */
 ZSTD_CCtx* ZSTD_createCCtx(void);
 size_t     ZSTD_freeCCtx(ZSTD_CCtx* cctx);                                   /* NULL is accepted */
-/* S/Compressor.cs:48-54 -> U/ZstdCompress.cs:819-884, 1270-1283 */
+/* S/Compressor.cs:48-54 -> U/ZstdCompress.cs:819-884, 1270-1283.  compressionLevel (negative levels included: fast strategy
+ * with a probing step and raw literals, as U/ZstdCompress.cs:7915-7920 + U/ZstdCompressInternal.cs:146-173), checksumFlag,
+ * dictIDFlag, strategy (1..9, mapped onto the three finders) and targetLength are honoured; windowLog >= 16, contentSizeFlag = 1,
+ * nbWorkers = 0, and for hashLog / minMatch / chainLog / searchLog the value the kernels implement (13; 6 or 5; the level's
+ * own) are accepted; anything else within bounds returns parameter_unsupported — nothing is silently ignored. */
 size_t     ZSTD_CCtx_setParameter(ZSTD_CCtx* cctx, int param, int value);
 size_t     ZSTD_CCtx_getParameter(const ZSTD_CCtx* cctx, int param, int* value);
 /* S/Compressor.cs:43-56 (dictionary load) -> U/ZstdCompress.cs:1286-1330, 5465-5503.  RAW-CONTENT dictionaries (any bytes
@@ -54,7 +58,8 @@ size_t     ZSTD_CCtx_loadDictionary(ZSTD_CCtx* cctx, const void* dict, size_t di
 size_t     ZSTD_compressBound(size_t srcSize);
 /* S/Compressor.cs:94 -> U/ZstdCompress.cs:7138-7177 */
 size_t     ZSTD_compress2(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
-/* B/Benchmark.cs:67, X/ExternMethods.cs:17-18 -> U/ZstdCompress.cs:5772-5776 */
+/* B/Benchmark.cs:67, X/ExternMethods.cs:17-18 -> U/ZstdCompress.cs:5751-5776: the level alone — default frame parameters, no
+ * dictionary even if one is loaded; the context's sticky parameters and dictionary are left as they are */
 size_t     ZSTD_compressCCtx(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int compressionLevel);
 /* S/Compressor.cs:8-9 -> U/ZstdCompress.cs:7762-7770 */
 int        ZSTD_minCLevel(void);
@@ -80,6 +85,10 @@ size_t     ZSTD_decompressDCtx(ZSTD_DCtx* dctx, void* dst, size_t dstCapacity, c
 /* ---- errors: S/ThrowHelper.cs:12-13 -> U/ErrorPrivate.cs:10-24, 35-120 ---- */
 unsigned    ZSTD_isError(size_t code);
 const char* ZSTD_getErrorName(size_t code);
+/* S/ThrowHelper.cs:18-24 (EnsureZdictSuccess) -> U/Zdict.cs:11-19.  The trainer itself (ZDICT_trainFromBuffer, S/DictBuilder.cs)
+ * is outside this library: a shim that keeps DictBuilder.cs routes that one call to the managed implementation. */
+unsigned    ZDICT_isError(size_t code);
+const char* ZDICT_getErrorName(size_t code);
 unsigned    ZSTD_versionNumber(void);        /* 10501, as U/ZstdCommon.cs:11-21 */
 const char* ZSTD_versionString(void);
 
@@ -92,7 +101,15 @@ const char* ZSTD_versionString(void);
 typedef struct { const void* src; size_t size; size_t pos; } ZSTD_inBuffer;
 typedef struct { void* dst; size_t size; size_t pos; } ZSTD_outBuffer;
 size_t ZSTD_compressStream2(ZSTD_CCtx* cctx, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp);
+/* frames whose window (or single-segment content size) exceeds 1 << ZSTD_d_windowLogMax (default 27) are refused with
+ * frameParameter_windowTooLarge as soon as their header has arrived (U/ZstdDecompress.cs:2965-2969) */
 size_t ZSTD_decompressStream(ZSTD_DCtx* dctx, ZSTD_outBuffer* output, ZSTD_inBuffer* input);
+/* buffer sizes the stream classes ask for: S/CompressionStream.cs:41 -> U/ZstdCompress.cs:6246-6249; S/DecompressionStream.cs:41 ->
+ * U/ZstdCompress.cs:6241-6244; U/ZstdDecompress.cs:2096-2104 */
+size_t ZSTD_CStreamInSize(void);
+size_t ZSTD_CStreamOutSize(void);
+size_t ZSTD_DStreamInSize(void);
+size_t ZSTD_DStreamOutSize(void);
 
 /* =====================================================================================================
  * Extensions (not in the reference): device selection, HBM-resident calls, per-stage timing, and test hooks.

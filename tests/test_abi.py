@@ -16,13 +16,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def _declared_symbols():
     text = open(os.path.join(ROOT, "include", "zstd_mi355x.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(ZSTD(?:MI)?_[A-Za-z0-9_]+)\s*\(", text)))
+    return sorted(set(re.findall(r"\b((?:ZSTD(?:MI)?|ZDICT)_[A-Za-z0-9_]+)\s*\(", text)))
 
 
 def test_library_exports_every_declared_symbol():
     lib = ctypes.CDLL(_ffi.LIB_PATH)
     names = _declared_symbols()
-    assert len(names) >= 38
+    assert len(names) >= 44 and "ZDICT_isError" in names and "ZSTD_CStreamOutSize" in names
     for n in names:
         assert hasattr(lib, n), f"{n} declared in include/zstd_mi355x.h but not exported"
         assert n in _ffi.SIGNATURES, f"{n} has no ctypes signature"
@@ -41,6 +41,17 @@ def test_levels_and_version():
     lib = _ffi.load()
     assert lib.ZSTD_minCLevel() == -131072 and lib.ZSTD_maxCLevel() == 22 and lib.ZSTD_defaultCLevel() == 3
     assert lib.ZSTD_versionNumber() == 10501 and lib.ZSTD_versionString() == b"1.5.1"
+
+
+def test_stream_buffer_sizes_and_zdict_helpers():
+    """What S/CompressionStream.cs:41, S/DecompressionStream.cs:41 and S/ThrowHelper.cs:18-24 bind to
+    (U/ZstdCompress.cs:6241-6249, U/ZstdDecompress.cs:2096-2104, U/Zdict.cs:11-19)."""
+    lib = _ffi.load()
+    assert lib.ZSTD_CStreamInSize() == 1 << 17
+    assert lib.ZSTD_CStreamOutSize() == lib.ZSTD_compressBound(1 << 17) + 3 + 4 == 131591
+    assert lib.ZSTD_DStreamInSize() == (1 << 17) + 3 and lib.ZSTD_DStreamOutSize() == 1 << 17
+    assert lib.ZDICT_isError((1 << 64) - 34) == 1 and lib.ZDICT_isError(1000) == 0
+    assert lib.ZDICT_getErrorName((1 << 64) - 34) == b"Cannot create Dictionary from provided samples"
 
 
 def test_error_convention():
@@ -66,6 +77,33 @@ def test_parameters_without_a_device():
     with pytest.raises(ZstdException) as e:
         c.SetParameter(400, 2)                             # nbWorkers: unsupported, as in the reference (U/ZstdCompress.cs:1064-1072)
     assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_unsupported
+    # match-finder parameters: bounds as ZSTD_cParam_getBounds; values the kernels implement are accepted and
+    # read back, other in-range values are refused loudly, 0 restores "from the level"
+    c.Level = 1
+    for param, ok, unsupported, out_of_bound in ((107, (1, 2, 3, 5, 9), (), (10, -1)),           # strategy
+                                                 (106, (0, 1, 7, 131072), (), (131073, -1)),      # targetLength
+                                                 (102, (13, 0), (12, 17), (5, 31)),               # hashLog
+                                                 (105, (6, 0), (5, 4), (2, 8)),                   # minMatch (fast strategy: 6)
+                                                 (103, (12, 0), (13,), (5, 31)),                  # chainLog (level 1, <= 128 KiB: 12)
+                                                 (104, (1, 0), (2,), (31,))):                    # searchLog
+        for v in ok:
+            c.SetParameter(param, v)
+            assert c.GetParameter(param) == v
+        for v in unsupported:
+            with pytest.raises(ZstdException) as e:
+                c.SetParameter(param, v)
+            assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_unsupported, (param, v)
+        for v in out_of_bound:
+            with pytest.raises(ZstdException) as e:
+                c.SetParameter(param, v)
+            assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_outOfBound, (param, v)
+        c.SetParameter(param, 0)
+    c.SetParameter(107, 2)
+    c.SetParameter(105, 5)                                 # doubleFast's short hash is 5 bytes wide
+    c.SetParameter(105, 0); c.SetParameter(107, 0)
+    c.Level = -5
+    assert c.GetParameter(100) == -5                       # negative levels are kept (U/ZstdCompress.cs:886-905)
+    c.Level = 1
     c.LoadDictionary(b"some dictionary bytes")             # raw content: kept on the host until a compression needs it
     c.LoadDictionary(None)
     c.LoadDictionary(bytes([0x37, 0xA4, 0x30, 0xEC]) + bytes(64))          # formatted: its header is validated on the device, i.e. at

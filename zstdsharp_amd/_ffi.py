@@ -44,6 +44,12 @@ SIGNATURES = {
     "ZSTD_versionString": (ctypes.c_char_p, []),
     "ZSTD_compressStream2": (c_size_t, [c_void_p, c_void_p, c_void_p, c_int]),
     "ZSTD_decompressStream": (c_size_t, [c_void_p, c_void_p, c_void_p]),
+    "ZSTD_CStreamInSize": (c_size_t, []),
+    "ZSTD_CStreamOutSize": (c_size_t, []),
+    "ZSTD_DStreamInSize": (c_size_t, []),
+    "ZSTD_DStreamOutSize": (c_size_t, []),
+    "ZDICT_isError": (c_uint, [c_size_t]),
+    "ZDICT_getErrorName": (ctypes.c_char_p, [c_size_t]),
     "ZSTDMI_deviceCount": (c_int, []),
     "ZSTDMI_CCtx_setDevice": (c_size_t, [c_void_p, c_int]),
     "ZSTDMI_DCtx_setDevice": (c_size_t, [c_void_p, c_int]),

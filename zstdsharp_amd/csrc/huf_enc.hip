@@ -271,7 +271,7 @@ __device__ __forceinline__ u32 min_gain(u32 srcSize) { return (srcSize >> 6) + 2
 // Front half: everything that is parallel over the literals or over the 256 symbols.  Hands the sorted leaves, the four
 // per-stream histograms and the verdicts to huf_tree_kernel through the chunk's (still unused) output slot.
 __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ lits, const ChunkMeta* __restrict__ meta,
-                                                       u8* __restrict__ slots)
+                                                       u8* __restrict__ slots, const u32 rawLiterals)
 {
     __shared__ HufBuildLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
@@ -283,7 +283,8 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
 #endif
 
     // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
-    if (litSize <= 63) return;                 // huf_tree_kernel stores them raw
+    // (rawLiterals: literal compression is off — the fast strategy with a step, i.e. negative levels; U/ZstdCompressInternal.cs:146-173)
+    if (litSize <= 63 || rawLiterals) return;  // huf_tree_kernel stores them raw
     for (u32 i = tid; i < 8 * 256; i += 256) (&L.hist[0][0][0])[i] = 0;
     for (u32 i = tid; i < 2 * 256; i += 256) (&L.sample[0][0])[i] = 0;
     for (u32 i = tid; i < 513; i += 256) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
@@ -403,7 +404,8 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
 // Back half: the serial constructions (HUF_buildTree, HUF_setMaxHeight, HUF_compressWeights) and the decisions.  One
 // wave per chunk and ~6 KiB of LDS, so that ~25 chunks per CU hide each other's LDS latency; per-symbol steps run
 // four symbols per lane.
-__global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ meta, HufTable* __restrict__ tables, const u8* __restrict__ slots)
+__global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ meta, HufTable* __restrict__ tables, const u8* __restrict__ slots,
+                                                      const u32 rawLiterals)
 {
     __shared__ HufTreeLds L;
     const u32 c = blockIdx.x, lane = threadIdx.x, tid = lane;
@@ -415,7 +417,7 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
     // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
-    if (litSize <= 63) {
+    if (litSize <= 63 || rawLiterals) {        // (or ZSTD_noCompressLiterals because literal compression is disabled, U/ZstdCompressLiterals.cs:99-101)
         if (tid == 0) { m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize; meta[c] = m; }
         return;
     }
@@ -693,10 +695,10 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     }
 }
 
-void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream)
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, hipStream_t stream)
 {
-    hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots);
-    hipLaunchKernelGGL(huf_tree_kernel, dim3(nChunks), dim3(64), 0, stream, meta, tables, slots);
+    hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots, rawLiterals);
+    hipLaunchKernelGGL(huf_tree_kernel, dim3(nChunks), dim3(64), 0, stream, meta, tables, slots, rawLiterals);
 }
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, hipStream_t stream)

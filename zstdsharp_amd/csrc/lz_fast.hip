@@ -150,16 +150,16 @@ __device__ __forceinline__ u32 next_match(const LzLds& L, u32 c, u32 par)
     return wj * 64 + ctz64(L.matchMask[wj]);
 }
 
-// MODE 0 = fast (one 6-byte hash, levels 1-2); 1 = dual (8-byte + SHORT-byte hashes, four candidates per position,
-// levels 3-5: the place of U/ZstdDoubleFast.cs:51-247 and of the greedy row-hash search U/ZstdLazy.cs:1101-1309);
-// 2 = dual + one-step lazy deferral (levels >= 6: U/ZstdLazy.cs:1836-1905)
+// MODE 0 = fast strategy (one 6-byte hash; levels 1-2 and the negative levels); 1 = doubleFast strategy (8-byte + SHORT-byte
+// hashes, four candidates per position; levels 3-4: the place of U/ZstdDoubleFast.cs:51-247); 2 = greedy and above (the dual
+// candidates + one-step lazy deferral; levels >= 5: the place of U/ZstdLazy.cs:1743-2032).  The host maps strategy -> MODE.
 // DICT: a dictionary prefix is present (its bounds checks fold away otherwise)
 template <int MODE, int SHORT, bool DICT>
 __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefix, const u32 prefixLen, const u32 chunkBytes,
-                                                  const u32 fhExtra)
+                                                  const u32 fhExtra, const u32 minStrideLog)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -291,6 +291,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         u32 strideSel = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);            // uniform
         if (prevDensity < 4 && prevStride >= 2) strideSel = prevStride < 4 ? prevStride + 1 : 4u;
         else if (prevDensity == 0 && !histTile && t != 0) strideSel = 3;                // nothing at all in the previous tile(s), whatever their stride
+        // negative levels (ZSTD_fast with a step, U/ZstdFast.cs:101-103): never denser than the step asks for; history is still inserted in full
+        if (strideSel < minStrideLog && !histTile) strideSel = minStrideLog;            // uniform
         // Super-tile: where only every 2nd / 4th (8th, 16th) position is probed, TWO / FOUR tiles (as many as are left in
         // full) are taken in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies
         // overlap and the two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot
@@ -724,7 +726,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream)
 {
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
@@ -733,7 +735,7 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -741,20 +743,20 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // prefix/prefixLen: the dictionary bytes every chunk sees as history (null/0 without one); chunkBytes = 64 KiB minus prefixLen
 // rounded up to whole 4 KiB tiles.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream)
 {
     if (prefixLen == 0 || chunkBytes >= kChunkSize) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, stream); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, stream); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, stream); break;
     }
 }
 

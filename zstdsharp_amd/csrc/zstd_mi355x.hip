@@ -10,14 +10,16 @@
 #include <vector>
 #include <cstring>
 #include <mutex>
+#include <new>
 #include "zmi_common.h"
+#include "zmi_cparams.h"
 #include "../../include/zstd_mi355x.h"
 
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, hipStream_t stream);
-void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream);
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
@@ -43,6 +45,13 @@ using namespace zmi;
 
 #define ZERR(code) ((size_t)0 - (size_t)(code))
 static inline bool isErr(size_t c) { return c > ZERR(kErrMaxCode); }
+// No C++ exception may cross the C ABI (the caller is P/Invoke): host-side container growth is the only thing that throws here.
+template <class F> static size_t guarded(F f)
+{
+    try { return f(); }
+    catch (const std::bad_alloc&) { return ZERR(kErrMemoryAllocation); }
+    catch (...) { return ZERR(kErrGeneric); }
+}
 
 namespace {
 
@@ -174,6 +183,43 @@ static size_t dctx_bind(ZSTD_DCtx* d)
     return 0;
 }
 
+// The parameters one compression call runs with: the context's sticky ones (ZSTD_compress2, ZSTD_compressStream2) or, for
+// ZSTD_compressCCtx, the level alone with default frame parameters and no dictionary (U/ZstdCompress.cs:5751-5776:
+// compress_usingDict(NULL) builds its parameters from the level and leaves the context's requested ones untouched).
+struct CallParams {
+    int level = 3, checksumFlag = 0, dictIDFlag = 1, strategy = 0, targetLength = 0;
+    bool useDict = true;
+};
+static CallParams sticky_params(const ZSTD_CCtx* c)
+{
+    CallParams p; p.level = c->level; p.checksumFlag = c->checksumFlag; p.dictIDFlag = c->dictIDFlag;
+    p.strategy = c->strategy; p.targetLength = c->targetLength; p.useDict = true;
+    return p;
+}
+
+// What a call resolves to: the reference's cParams for (level, chunk size) with the explicitly set strategy /
+// targetLength on top (ZSTD_overrideCParams, U/ZstdCompress.cs:2096-2127), then the parts of them the kernels act on.
+struct Resolved { CParams cp; u32 finder, minStrideLog, rawLiterals; };
+static Resolved resolve_call(const CallParams& p, size_t srcSize, u32 chunkBytes)
+{
+    Resolved r;
+    r.cp = get_cparams(p.level, srcSize < chunkBytes ? srcSize : chunkBytes);
+    if (p.strategy) r.cp.strategy = (u32)p.strategy;
+    if (p.targetLength) r.cp.targetLength = (u32)p.targetLength;
+    // match finder by strategy (U/ZstdCompress.cs:3397-3417 selects the block compressor the same way): fast; doubleFast -> the
+    // dual-hash finder; greedy and everything above it -> dual-hash + lazy deferral (no lazy2 / binary-tree / optimal parsers)
+    r.finder = r.cp.strategy <= kStratFast ? 0u : r.cp.strategy == kStratDfast ? 1u : 2u;
+    // ZSTD_fast probes two of every targetLength + 2 positions once a step is set (negative levels; U/ZstdFast.cs:101-103,
+    // 130-136): the tile finder's counterpart is its probing stride, a power of two
+    r.minStrideLog = 0;
+    if (r.cp.strategy == kStratFast && r.cp.targetLength > 1) {
+        const u32 gap = (r.cp.targetLength + 2) / 2;
+        r.minStrideLog = cp_highbit32(gap); if (r.minStrideLog > 4) r.minStrideLog = 4;
+    }
+    r.rawLiterals = literals_compression_disabled(r.cp) ? 1u : 0u;
+    return r;
+}
+
 static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
 {
     return c->seqs.ensure((size_t)nChunks * kMaxSeq * sizeof(Seq)) && c->lits.ensure((size_t)nChunks * kLitStride + 64) &&
@@ -181,13 +227,6 @@ static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
            c->slots.ensure((size_t)nChunks * kSlotStride + 64) && c->offsets.ensure((size_t)nChunks * sizeof(u64)) &&
            c->total.ensure(64);
 }
-
-// strategy the entropy stage should assume for a level (U/Clevels.cs rows for <= 128 KiB inputs)
-// (the encoding-type choice of ZSTD_selectEncodingType is the < ZSTD_lazy heuristic for every level: U/ZstdCompressSequences.cs:400-469)
-static u32 strategy_for_level(int level) { (void)level; return 1; }
-// match finder per level, following the strategy column of U/Clevels.cs:488-495 (<= 128 KiB rows): levels <= 2 fast,
-// 3-4 doubleFast -> the dual-hash finder, >= 5 greedy/lazy -> dual-hash + lazy deferral.  See lz_fast.hip.
-static u32 finder_for_level(int level) { return level <= 2 ? 0u : level <= 4 ? 1u : 2u; }
 
 // upload a newly loaded dictionary; a formatted one is first validated on the device (ZSTD_loadCEntropy's checks are those of
 // ZSTD_loadDEntropy plus the symbol-coverage rules that only matter to an encoder reusing the tables) -> dictionary_corrupted
@@ -216,33 +255,35 @@ static size_t cctx_sync_dictionary(ZSTD_CCtx* c)
 }
 
 // the compress pipeline over device-resident buffers
-static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
 {
     hipStream_t s = c->stream;
     if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
         u8 f[13]; size_t n = 0;
         f[n++] = 0x28; f[n++] = 0xB5; f[n++] = 0x2F; f[n++] = 0xFD;
-        f[n++] = (u8)((c->checksumFlag ? 4 : 0) | 0x20); f[n++] = 0;
+        f[n++] = (u8)((cp.checksumFlag ? 4 : 0) | 0x20); f[n++] = 0;
         f[n++] = 1; f[n++] = 0; f[n++] = 0;
-        if (c->checksumFlag) { f[n++] = 0x99; f[n++] = 0xE9; f[n++] = 0xD8; f[n++] = 0x51; }   // XXH64("") low 32 bits = 0x51D8E999
+        if (cp.checksumFlag) { f[n++] = 0x99; f[n++] = 0xE9; f[n++] = 0xD8; f[n++] = 0x51; }   // XXH64("") low 32 bits = 0x51D8E999
         if (dstCapacity < n) return ZERR(kErrDstSizeTooSmall);
         if (hipMemcpyAsync(d_dst, f, n, hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
         (void)hipStreamSynchronize(s);
         return n;
     }
-    { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
-    const u32 prefixLen = dict_prefix_len(c, srcSize);
+    if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
+    const u32 prefixLen = cp.useDict ? dict_prefix_len(c, srcSize) : 0u;
     const u32 chunkBytes = kChunkSize - round_tile(prefixLen);
     // a formatted dictionary: its dictID in every frame header (unless ZSTD_c_dictIDFlag = 0), its repcodes in front of every frame
-    const u32 dictID = c->dictFormatted ? c->info.dictID : 0u;
-    const u32 dictIdBytes = (dictID && c->dictIDFlag) ? (dictID < 256 ? 1u : dictID < 65536 ? 2u : 4u) : 0u;
+    const bool fmtDict = cp.useDict && c->dictFormatted;
+    const u32 dictID = fmtDict ? c->info.dictID : 0u;
+    const u32 dictIdBytes = (dictID && cp.dictIDFlag) ? (dictID < 256 ? 1u : dictID < 65536 ? 2u : 4u) : 0u;
     const u32 plainReps[3] = { 1, 4, 8 };
-    const u32* const initReps = c->dictFormatted ? c->info.rep : plainReps;
+    const u32* const initReps = fmtDict ? c->info.rep : plainReps;
+    const Resolved rs = resolve_call(cp, srcSize, chunkBytes);
     const u8* prefix = prefixLen ? (const u8*)c->dict.p + (c->dictHost.size() - prefixLen) : nullptr;
     const u64 totalChunks = (srcSize + chunkBytes - 1) / chunkBytes;
     const u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
-    const u32 strategy = strategy_for_level(c->level);
+    const u32 strategy = rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy;      // ZSTD_selectEncodingType's < lazy heuristic is the one seq_encode holds (U/ZstdCompressSequences.cs:400-469): levels whose strategy is lazy or above get greedy's constants
     size_t produced = 0;
     bool first = true;
     for (u64 c0 = 0; c0 < totalChunks; c0 += passChunks) {
@@ -252,10 +293,10 @@ static size_t compress_device(ZSTD_CCtx* c, u8* d_dst, size_t dstCapacity, const
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(finder_for_level(c->level), src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, s);                      c->timer.mark("lz_fast", s);
-        launch_huf_build(lits, meta, tables, slots, nChunks, s);                        c->timer.mark("huf_build", s);
-        if (c->checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             c->timer.mark("xxh64", s); }
-        launch_seq_encode(seqs, meta, slots, nChunks, strategy, c->checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, s);   c->timer.mark("seq_encode", s);
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, s);      c->timer.mark("lz_fast", s);
+        launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, s);        c->timer.mark("huf_build", s);
+        if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             c->timer.mark("xxh64", s); }
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, s);   c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
@@ -307,7 +348,7 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
         if (value < ZSTD_minCLevel()) value = ZSTD_minCLevel();
         if (value > ZSTD_maxCLevel()) value = ZSTD_maxCLevel();
         c->level = value == 0 ? 3 : value;
-        return (size_t)c->level;
+        return c->level >= 0 ? (size_t)c->level : 0;        /* a size_t cannot carry a negative level (U/ZstdCompress.cs:899-905) */
     case ZSTD_c_checksumFlag:    if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound); c->checksumFlag = value; return (size_t)value;
     case ZSTD_c_contentSizeFlag: if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound);
                                  if (value == 0) return ZERR(kErrParameterUnsupported);   /* the GPU framing needs sized frames */
@@ -317,9 +358,28 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
     case ZSTD_c_windowLog:       if (value != 0 && (value < 10 || value > 31)) return ZERR(kErrParameterOutOfBound);
                                  if (value != 0 && value < (int)kChunkLog) return ZERR(kErrParameterUnsupported);   /* frames are 64 KiB single-segment */
                                  c->windowLog = value; return (size_t)value;
-    case ZSTD_c_hashLog: case ZSTD_c_chainLog: case ZSTD_c_searchLog: case ZSTD_c_minMatch: case ZSTD_c_targetLength: case ZSTD_c_strategy:
-        if (value != 0) return ZERR(kErrParameterUnsupported);      /* match-finder geometry is fixed by the kernels */
-        return 0;
+    // Match-finder parameters (bounds: ZSTD_cParam_getBounds, U/ZstdCompress.cs:444-700).  0 = "from the level".  A value the
+    // kernels implement is accepted and stored; any other value within bounds is parameter_unsupported, never silently ignored.
+    case ZSTD_c_strategy:        // every strategy maps onto one of the three finders (resolve_call)
+        if (value < 0 || value > 9) return ZERR(kErrParameterOutOfBound);
+        c->strategy = value; return (size_t)value;
+    case ZSTD_c_targetLength:    // fast strategy: acceleration (the probing stride) and, when > 0, raw literals; otherwise no effect on the finders
+        if (value < 0 || value > (1 << 17)) return ZERR(kErrParameterOutOfBound);
+        c->targetLength = value; return (size_t)value;
+    case ZSTD_c_hashLog:         // the LDS tables have 2^13 buckets whatever the level's row says
+        if (value != 0 && (value < 6 || value > 30)) return ZERR(kErrParameterOutOfBound);
+        if (value != 0 && value != (int)kKernelHashLog) return ZERR(kErrParameterUnsupported);
+        c->hashLog = value; return (size_t)value;
+    case ZSTD_c_minMatch: {      // width of the finder's hash: 6 (fast), 5 (the others)
+        if (value != 0 && (value < 3 || value > 7)) return ZERR(kErrParameterOutOfBound);
+        const CParams cp = get_cparams(c->level, kChunkSize);
+        if (value != 0 && value != (int)kernel_min_match(c->strategy ? (u32)c->strategy : cp.strategy)) return ZERR(kErrParameterUnsupported);
+        c->minMatch = value; return (size_t)value; }
+    case ZSTD_c_chainLog: case ZSTD_c_searchLog: {   // no chain and no search depth in the tile finders: only the level's own value is accepted
+        if (value != 0 && (value < (param == ZSTD_c_chainLog ? 6 : 1) || value > 30)) return ZERR(kErrParameterOutOfBound);
+        const CParams cp = get_cparams(c->level, kChunkSize);
+        if (value != 0 && value != (int)(param == ZSTD_c_chainLog ? cp.chainLog : cp.searchLog)) return ZERR(kErrParameterUnsupported);
+        (param == ZSTD_c_chainLog ? c->chainLog : c->searchLog) = value; return (size_t)value; }
     default: return ZERR(kErrParameterUnsupported);
     }
 }
@@ -334,8 +394,12 @@ size_t ZSTD_CCtx_getParameter(const ZSTD_CCtx* c, int param, int* value)
     case ZSTD_c_dictIDFlag: *value = c->dictIDFlag; return 0;
     case ZSTD_c_nbWorkers: *value = 0; return 0;
     case ZSTD_c_windowLog: *value = c->windowLog; return 0;
-    case ZSTD_c_hashLog: case ZSTD_c_chainLog: case ZSTD_c_searchLog: case ZSTD_c_minMatch: case ZSTD_c_targetLength: case ZSTD_c_strategy:
-        *value = 0; return 0;
+    case ZSTD_c_hashLog: *value = c->hashLog; return 0;            // the requested values, 0 = from the level (U/ZstdCompress.cs:1100-1150)
+    case ZSTD_c_chainLog: *value = c->chainLog; return 0;
+    case ZSTD_c_searchLog: *value = c->searchLog; return 0;
+    case ZSTD_c_minMatch: *value = c->minMatch; return 0;
+    case ZSTD_c_targetLength: *value = c->targetLength; return 0;
+    case ZSTD_c_strategy: *value = c->strategy; return 0;
     default: return ZERR(kErrParameterUnsupported);
     }
 }
@@ -343,7 +407,7 @@ size_t ZSTD_CCtx_getParameter(const ZSTD_CCtx* c, int param, int* value)
 // ZSTD_compress_insertDictionary, U/ZstdCompress.cs:5465-5503: without the magic the bytes are raw content
 // (ZSTD_loadDictionaryContent, :5126-5237) and the frames carry no dictID, exactly as the reference writes them; with it, a
 // formatted dictionary (ZSTD_loadZstdDictionary, :5402-5463).
-size_t ZSTD_CCtx_loadDictionary(ZSTD_CCtx* c, const void* dict, size_t dictSize)
+static size_t ZSTD_CCtx_loadDictionary_impl(ZSTD_CCtx* c, const void* dict, size_t dictSize)
 {
     if (!c) return ZERR(kErrGeneric);
     if (!c->sIn.empty() || c->sEnding) return ZERR(kErrStageWrong);        /* not in the middle of a streaming frame session, U/ZstdCompress.cs:1273 */
@@ -381,10 +445,10 @@ size_t ZSTDMI_compressDevice(ZSTD_CCtx* c, void* d_dst, size_t dstCapacity, cons
     if (srcSize && !d_src) return ZERR(kErrSrcSizeWrong);
     if (!d_dst && dstCapacity) return ZERR(kErrDstBufferNull);
     if (!d_dst) return ZERR(kErrDstSizeTooSmall);
-    return compress_device(c, (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
+    return compress_device(c, sticky_params(c), (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
 }
 
-size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+static size_t compress_any(ZSTD_CCtx* c, const CallParams& cp, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
     size_t e = cctx_bind(c); if (isErr(e)) return e;
     if (srcSize && !src) return ZERR(kErrSrcSizeWrong);
@@ -403,7 +467,7 @@ size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* s
         if (!c->stageDst.ensure(devCap + 64)) return ZERR(kErrMemoryAllocation);
         d_dst = (u8*)c->stageDst.p;
     }
-    const size_t r = compress_device(c, d_dst, devCap, d_src, srcSize);
+    const size_t r = compress_device(c, cp, d_dst, devCap, d_src, srcSize);
     if (isErr(r)) return r;
     if (!dstDev) {
         if (hipMemcpyAsync(dst, d_dst, r, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZERR(kErrGeneric);
@@ -412,16 +476,29 @@ size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* s
     return r;
 }
 
+size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    if (!c) return ZERR(kErrGeneric);
+    return compress_any(c, sticky_params(c), dst, dstCapacity, src, srcSize);
+}
+
 size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
 {
     if (!c) return ZERR(kErrGeneric);
-    // ZSTD_compressCCtx = compress_usingDict(NULL) with this level and default frame parameters (U/ZstdCompress.cs:5772-5776)
-    const int savedLevel = c->level, savedChk = c->checksumFlag;
-    c->level = level == 0 ? 3 : level; c->checksumFlag = 0;
-    const size_t r = ZSTD_compress2(c, dst, dstCapacity, src, srcSize);
-    c->level = savedLevel; c->checksumFlag = savedChk;
-    return r;
+    // ZSTD_compressCCtx = ZSTD_compress_usingDict(dict = NULL, level) (U/ZstdCompress.cs:5751-5776): the level alone, default
+    // frame parameters (content size, no checksum), NO dictionary even if one is loaded; the context's sticky parameters and
+    // its dictionary stay as they are for later ZSTD_compress2 calls.
+    CallParams p; p.level = level == 0 ? 3 : (level < ZSTD_minCLevel() ? ZSTD_minCLevel() : level > ZSTD_maxCLevel() ? ZSTD_maxCLevel() : level);
+    p.useDict = false;
+    return compress_any(c, p, dst, dstCapacity, src, srcSize);
 }
+
+/* S/CompressionStream.cs:41, S/DecompressionStream.cs:41 size their buffers with these (U/ZstdCompress.cs:6241-6249,
+ * U/ZstdDecompress.cs:2096-2104): one block in, one compressed block + header + checksum out */
+size_t ZSTD_CStreamInSize(void)  { return (size_t)1 << 17; }
+size_t ZSTD_CStreamOutSize(void) { return ZSTD_compressBound((size_t)1 << 17) + 3 + 4; }
+size_t ZSTD_DStreamInSize(void)  { return ((size_t)1 << 17) + 3; }
+size_t ZSTD_DStreamOutSize(void) { return (size_t)1 << 17; }
 
 // ---------------- decompression ----------------
 ZSTD_DCtx* ZSTD_createDCtx(void) { return new (std::nothrow) ZSTD_DCtx_s(); }
@@ -453,7 +530,7 @@ size_t ZSTD_DCtx_getParameter(ZSTD_DCtx* d, int param, int* value)
 // ZSTD_decompress_insertDictionary, U/ZstdDecompress.cs:1909-1931: without the magic the bytes are raw content, history in
 // front of every frame (ZSTD_refDictContent, :1758-1771); with it (0xEC30A437) the header's Huffman and FSE tables and
 // repcodes are what every frame starts from and frames must name its dictID or none (ZSTD_loadDEntropy, :1773-1875).
-size_t ZSTD_DCtx_loadDictionary(ZSTD_DCtx* d, const void* dict, size_t dictSize)
+static size_t ZSTD_DCtx_loadDictionary_impl(ZSTD_DCtx* d, const void* dict, size_t dictSize)
 {
     if (!d) return ZERR(kErrGeneric);
     if (dict == nullptr || dictSize == 0) { d->dictHost.clear(); d->dictDirty = true; return 0; }
@@ -514,6 +591,27 @@ static size_t host_frame_size_info(const u8* src, size_t srcSize, unsigned long 
     return (size_t)(ip - src);
 }
 
+// Window size a frame header declares (ZSTD_getFrameHeader_advanced, U/ZstdDecompress.cs:462-634): the window descriptor, or the
+// content size of a single-segment frame.  0 = not a zstd frame header, or not all of it is there yet.
+static u64 host_frame_window(const u8* src, size_t srcSize)
+{
+    auto rd32 = [](const u8* p) { return (u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24); };
+    if (srcSize < 5 || rd32(src) != 0xFD2FB528u) return 0;
+    const u8 fhd = src[4];
+    static const size_t did[4] = { 0, 1, 2, 4 }, fcsB[4] = { 0, 2, 4, 8 };
+    const u32 single = (fhd >> 5) & 1, fcsId = fhd >> 6;
+    const size_t fhs = 5 + !single + did[fhd & 3] + fcsB[fcsId] + (single && !fcsId);
+    if (srcSize < fhs) return 0;
+    if (!single) { const u8 wl = src[5]; const u32 wlog = (wl >> 3) + 10; if (wlog > 31) return ~0ull; const u64 w = 1ull << wlog; return w + (w >> 3) * (wl & 7); }
+    const size_t pos = 5 + did[fhd & 3];
+    switch (fcsId) {
+    case 0: return src[pos];
+    case 1: return (u64)((u32)src[pos] | ((u32)src[pos + 1] << 8)) + 256;
+    case 2: return rd32(src + pos);
+    default: return (u64)rd32(src + pos) | ((u64)rd32(src + pos + 4) << 32);
+    }
+}
+
 static const u8* host_view(const void* src, size_t srcSize, std::vector<u8>& tmp)
 {
     if (!is_device_ptr(src)) return (const u8*)src;
@@ -522,7 +620,7 @@ static const u8* host_view(const void* src, size_t srcSize, std::vector<u8>& tmp
     return tmp.data();
 }
 
-unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize)
+static unsigned long long ZSTD_decompressBound_impl(const void* src, size_t srcSize)
 {
     std::vector<u8> tmp; const u8* ip = srcSize ? host_view(src, srcSize, tmp) : (const u8*)src;
     if (srcSize && !ip) return (unsigned long long)0 - 2;
@@ -534,13 +632,13 @@ unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize)
     }
     return bound;
 }
-size_t ZSTD_findFrameCompressedSize(const void* src, size_t srcSize)
+static size_t ZSTD_findFrameCompressedSize_impl(const void* src, size_t srcSize)
 {
     std::vector<u8> tmp; const u8* ip = host_view(src, srcSize, tmp);
     if (!ip) return ZERR(kErrSrcSizeWrong);
     unsigned long long b; return host_frame_size_info(ip, srcSize, &b);
 }
-unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
+static unsigned long long ZSTD_getFrameContentSize_impl(const void* src, size_t srcSize)
 {
     std::vector<u8> tmp; const size_t look = srcSize < 18 ? srcSize : 18;
     const u8* ip = look ? host_view(src, look, tmp) : nullptr;
@@ -644,14 +742,14 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     return (size_t)total;
 }
 
-size_t ZSTDMI_decompressDevice(ZSTD_DCtx* d, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
+static size_t ZSTDMI_decompressDevice_impl(ZSTD_DCtx* d, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
 {
     size_t e = dctx_bind(d); if (isErr(e)) return e;
     if (srcSize && !d_src) return ZERR(kErrSrcSizeWrong);
     return decompress_device(d, (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
 }
 
-size_t ZSTD_decompressDCtx(ZSTD_DCtx* d, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+static size_t ZSTD_decompressDCtx_impl(ZSTD_DCtx* d, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
     size_t e = dctx_bind(d); if (isErr(e)) return e;
     if (srcSize && !src) return ZERR(kErrSrcSizeWrong);
@@ -711,6 +809,9 @@ const char* ZSTD_getErrorName(size_t code)
     default: return "Unspecified error code";
     }
 }
+/* S/ThrowHelper.cs:18-24 (EnsureZdictSuccess) -> U/Zdict.cs:11-19: the dictionary builder's error helpers are the common ones */
+unsigned ZDICT_isError(size_t code) { return isErr(code); }
+const char* ZDICT_getErrorName(size_t code) { return ZSTD_getErrorName(code); }
 unsigned ZSTD_versionNumber(void) { return 10501; }
 const char* ZSTD_versionString(void) { return "1.5.1"; }
 
@@ -738,7 +839,7 @@ static size_t cstream_compress(ZSTD_CCtx* c, size_t n)      // first n buffered 
     c->sIn.erase(c->sIn.begin(), c->sIn.begin() + (ptrdiff_t)n);
     return 0;
 }
-size_t ZSTD_compressStream2(ZSTD_CCtx* c, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp)
+static size_t ZSTD_compressStream2_impl(ZSTD_CCtx* c, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp)
 {
     if (!c || !output || !input) return ZERR(kErrGeneric);
     if (output->pos > output->size) return ZERR(104);          // dstBuffer_wrong
@@ -783,7 +884,7 @@ static size_t dstream_drain(ZSTD_DCtx* d, ZSTD_outBuffer* o)
     if (d->dOutPos == d->dOut.size()) { d->dOut.clear(); d->dOutPos = 0; }
     return d->dOut.size() - d->dOutPos;
 }
-size_t ZSTD_decompressStream(ZSTD_DCtx* d, ZSTD_outBuffer* output, ZSTD_inBuffer* input)
+static size_t ZSTD_decompressStream_impl(ZSTD_DCtx* d, ZSTD_outBuffer* output, ZSTD_inBuffer* input)
 {
     if (!d || !output || !input) return ZERR(kErrGeneric);
     if (output->pos > output->size) return ZERR(104);
@@ -798,13 +899,18 @@ size_t ZSTD_decompressStream(ZSTD_DCtx* d, ZSTD_outBuffer* output, ZSTD_inBuffer
         size_t whole = 0; unsigned long long bound = 0;
         while (whole < d->dIn.size()) {
             unsigned long long b = 0;
+            // ZSTD_d_windowLogMax bounds what a streamed frame may ask for (U/ZstdDecompress.cs:2966-2969, with the 1 KiB floor of
+            // :2965): checked as soon as the header is there, before the frame is collected or anything is sized from it
+            { u64 w = host_frame_window(d->dIn.data() + whole, d->dIn.size() - whole);
+              if (w && w < 1024) w = 1024;
+              if (w > (1ull << d->windowLogMax)) { d->dIn.clear(); return ZERR(kErrWindowTooLarge); } }
             const size_t fs = host_frame_size_info(d->dIn.data() + whole, d->dIn.size() - whole, &b);
             if (isErr(fs)) { if (fs == ZERR(kErrSrcSizeWrong)) break; return fs; }          // incomplete frame: wait for more input
             whole += fs; bound += b;
         }
         if (whole) {
             d->dOut.resize((size_t)bound); d->dOutPos = 0;
-            const size_t r = ZSTD_decompressDCtx(d, d->dOut.data(), d->dOut.size(), d->dIn.data(), whole);
+            const size_t r = ZSTD_decompressDCtx_impl(d, d->dOut.data(), d->dOut.size(), d->dIn.data(), whole);
             if (isErr(r)) { d->dOut.clear(); return r; }
             d->dOut.resize(r);
             d->dIn.erase(d->dIn.begin(), d->dIn.begin() + (ptrdiff_t)whole);
@@ -869,10 +975,11 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (nbSeq) (void)hipMemcpyAsync(c->seqs.p, seqs, nbSeq * sizeof(Seq), hipMemcpyHostToDevice, s);
     if (litSize) (void)hipMemcpyAsync(c->lits.p, lits, litSize, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
-    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, s);
+    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, 0, s);
     launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, s);
     { const u32 plainReps[3] = { 1, 4, 8 };
-      launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, strategy_for_level(c->level), 0, 0, 0, 0, plainReps, s); }
+      const Resolved rs = resolve_call(sticky_params(c), srcSize, kChunkSize);
+      launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy, 0, 0, 0, 0, plainReps, s); }
     if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     if (m.blockType != 2) return 0;
@@ -880,6 +987,23 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (hipMemcpy(dst, (u8*)c->slots.p + m.fhSize + 3, m.bodySize, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
     c->lastChunks = 1;
     return m.bodySize;
+}
+
+// ---------------- entry points whose host-side containers may throw: guarded (see guarded()) ----------------
+size_t ZSTD_CCtx_loadDictionary(ZSTD_CCtx* c, const void* dict, size_t dictSize) { return guarded([&] { return ZSTD_CCtx_loadDictionary_impl(c, dict, dictSize); }); }
+size_t ZSTD_DCtx_loadDictionary(ZSTD_DCtx* d, const void* dict, size_t dictSize) { return guarded([&] { return ZSTD_DCtx_loadDictionary_impl(d, dict, dictSize); }); }
+size_t ZSTD_findFrameCompressedSize(const void* src, size_t srcSize) { return guarded([&] { return ZSTD_findFrameCompressedSize_impl(src, srcSize); }); }
+size_t ZSTD_decompressDCtx(ZSTD_DCtx* d, void* dst, size_t dstCapacity, const void* src, size_t srcSize) { return guarded([&] { return ZSTD_decompressDCtx_impl(d, dst, dstCapacity, src, srcSize); }); }
+size_t ZSTDMI_decompressDevice(ZSTD_DCtx* d, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize) { return guarded([&] { return ZSTDMI_decompressDevice_impl(d, d_dst, dstCapacity, d_src, srcSize); }); }
+size_t ZSTD_compressStream2(ZSTD_CCtx* c, ZSTD_outBuffer* output, ZSTD_inBuffer* input, int endOp) { return guarded([&] { return ZSTD_compressStream2_impl(c, output, input, endOp); }); }
+size_t ZSTD_decompressStream(ZSTD_DCtx* d, ZSTD_outBuffer* output, ZSTD_inBuffer* input) { return guarded([&] { return ZSTD_decompressStream_impl(d, output, input); }); }
+unsigned long long ZSTD_decompressBound(const void* src, size_t srcSize)
+{
+    try { return ZSTD_decompressBound_impl(src, srcSize); } catch (...) { return (unsigned long long)0 - 2; }      /* ZSTD_CONTENTSIZE_ERROR */
+}
+unsigned long long ZSTD_getFrameContentSize(const void* src, size_t srcSize)
+{
+    try { return ZSTD_getFrameContentSize_impl(src, srcSize); } catch (...) { return (unsigned long long)0 - 2; }      /* ZSTD_CONTENTSIZE_ERROR */
 }
 
 } // extern "C"

@@ -48,9 +48,7 @@ class Decompressor:
                                     f"Decompressed content size {expected} is greater than {maxDecompressedSize}")
             out = ctypes.create_string_buffer(max(expected, 1))
             n = ensure_zstd_success(self._lib, self._lib.ZSTD_decompressDCtx(self.dctx, out, expected, saddr, sn))
-            if n != expected:
-                raise ZstdException(ZSTD_ErrorCode.ZSTD_error_GENERIC, "Decompressed content size is not as expected")
-            return out.raw[:n]
+            return out.raw[:n]          # new Span<byte>(dest, 0, length): `expected` is a bound, not a promise (S/Decompressor.cs:63-75)
         daddr, dn, dkeep = _as_buffer(dest)
         return ensure_zstd_success(self._lib, self._lib.ZSTD_decompressDCtx(self.dctx, (daddr + offset) if daddr else None, dn - offset, saddr, sn))
 

@@ -33,7 +33,7 @@ class CompressionStream:
         self.innerStream = stream
         self._own = compressor is None
         self.compressor = compressor if compressor is not None else Compressor(level)
-        self._outSize = bufferSize if bufferSize > 0 else 1 << 17
+        self._outSize = bufferSize if bufferSize > 0 else ensure_zstd_success(self._lib, self._lib.ZSTD_CStreamOutSize())      # S/CompressionStream.cs:40-41
         self._out = ctypes.create_string_buffer(self._outSize)
         self._leaveOpen = leaveOpen
         self._disposed = False
@@ -95,7 +95,7 @@ class DecompressionStream:
         self.innerStream = stream
         self._own = decompressor is None
         self.decompressor = decompressor if decompressor is not None else Decompressor()
-        self._inSize = bufferSize if bufferSize > 0 else (1 << 17) + 3
+        self._inSize = bufferSize if bufferSize > 0 else ensure_zstd_success(self._lib, self._lib.ZSTD_CStreamInSize())          # S/DecompressionStream.cs:41 (the reference asks the C-stream size here)
         self._inBuf = ctypes.create_string_buffer(self._inSize)
         self._input = ZSTD_inBuffer(ctypes.addressof(self._inBuf), 0, 0)
         self._last = 0
