@@ -238,7 +238,8 @@ def test_output_is_deterministic(ctxs):
 def test_ratio_stays_near_the_reference_parse(ctxs, oracle):
     """The wavefront-parallel parse may lose a little against ZSTD_fast's serial parse, not a lot."""
     c, _ = ctxs
-    for kind, slack in (("zipf", 1.01), ("text", 1.06), ("runs", 1.6), ("mixed", 1.15), ("bytei", 1.05), ("period", 1.3)):
+    # slack = measured on MI355X (round 2: 1.0001, 1.0111, 1.4821, 1.0034, 1.0000, 1.0000) + 2 %
+    for kind, slack in (("zipf", 1.02), ("text", 1.032), ("runs", 1.51), ("mixed", 1.024), ("bytei", 1.02), ("period", 1.02)):
         data = datagen.gen(kind, 1 << 20, 6)
         gpu, ref = len(c.Wrap(data)), len(oracle.compress(data, 1, 0, 65536))
         print(f"ratio-vs-oracle L1 {kind}: gpu {gpu} ref {ref} = {gpu / ref:.4f}")
@@ -344,7 +345,7 @@ def test_levels_buy_ratio(gpu_lib, oracle):
         assert sizes[(kind, 3)] <= sizes[(kind, 1)] * 1.005, (kind, sizes)
         assert sizes[(kind, 5)] <= sizes[(kind, 3)] * 1.005, (kind, sizes)
         assert sizes[(kind, 7)] <= sizes[(kind, 5)] * 1.005, (kind, sizes)
-        for level, slack in ((3, 1.08), (5, 1.12)):
+        for level, slack in ((3, 1.055), (5, 1.035)):        # measured (round 2): text 1.0328 / 1.0136, mixed 1.0108 / 0.9940, + 2 %
             ref = len(oracle.compress(data, level, 0, 65536))
             print(f"ratio-vs-oracle L{level} {kind}: gpu {sizes[(kind, level)]} ref {ref} = {sizes[(kind, level)] / ref:.4f}")
             assert sizes[(kind, level)] <= ref * slack + 64, (kind, level, sizes[(kind, level)], ref)

@@ -79,14 +79,60 @@ struct DictInfo {
     u32 pad[3];
 };
 
+// The decoder's work lists (decode_walk.hip builds them).  A frame is a run of blocks; blocks are the
+// unit every parallel stage works on: a block's literals and its three FSE state chains depend on nothing but the tables the
+// pre-pass resolves for it (U/ZstdDecompressBlock.cs:197-207, 1780-1786), only the LZ execution is ordered inside a frame.
 struct FrameDesc {      // one per frame found by the frame walk (U/ZstdDecompress.cs:877-951)
     u64 srcOff;         // offset of the frame in the compressed input
-    u64 dstOff;         // offset of its content in the output
-    u32 srcSize;        // compressed frame size
-    u32 dstSize;        // content size; for a frame without one (unsized = 1) the bound nbBlocks x blockSizeMax (U/ZstdDecompress.cs:877-951)
-    u32 unsized;        // 1 = the header carries no content size: the decoder reports the regenerated size instead of checking it
-    u32 pad;
+    u64 dstOff;         // offset of its content in the output (frames without a content size: after their regenerated sizes are known)
+    u64 scratchOff;     // offset of its literals in the literal scratch: the content-size (or bound) prefix sum the walk produced
+    u64 srcSize;        // compressed frame size
+    u64 dstSize;        // content size; for a frame without one the bound nbBlocks x blockSizeMax until the regenerated size replaces it
+    u32 firstBlock, nbBlocks;
+    u32 unsized;        // 1 = the header carries no content size
+    u32 checksum;       // 1 = a 4-byte XXH64 checksum follows the last block
 };
+
+constexpr u32 kNoBlock   = 0xFFFFFFFFu;     // table source: nothing defined it (corruption, or the default where that is legal)
+constexpr u32 kDictBlock = 0xFFFFFFFEu;     // table source: the formatted dictionary
+
+// One block of a frame.  Filled in stages: the walk (position, type, size), block_parse (the sections of a compressed block),
+// block_link (where repeat-mode tables and treeless literals come from, literal offsets, record offsets), seq_decode (regenerated
+// size, repcode transfer), block_offsets (output offset, repcodes at the block's start).
+struct BlockDesc {
+    u64 srcOff;         // the block's body in the compressed input (absolute; behind its 3-byte header)
+    u64 dstRel;         // output offset relative to its frame's
+    u64 litRel;         // offset of its regenerated literals relative to the frame's scratch (Huffman-coded literals sections only)
+    u64 seqBase;        // index of its first sequence record
+    u32 frame;
+    u32 bsz;            // body bytes in the input (an RLE block: 1)
+    u32 outSize;        // regenerated bytes: raw/RLE from the header; compressed: litSize when it has no sequences, else from seq_decode
+    u8  type, last, litType, litSingle;     // block type 0 raw 1 RLE 2 compressed; literals section type 0 raw 1 RLE 2 compressed 3 treeless
+    u32 litSize, litCSize;
+    u32 lhSize;         // literals section header bytes
+    u32 hufSrc;         // block whose literals section holds this block's Huffman table description (itself, an earlier one, kDictBlock)
+    u32 nbSeq;
+    u32 modes;          // the symbol-compression-modes byte (LL << 6 | OF << 4 | ML << 2)
+    u32 tblOff[3];      // LL, OF, ML table descriptions inside the body (RLE byte or NCount), where the mode has one
+    u32 bitsOff;        // start of the sequence bitstream inside the body
+    u32 tblSrc[3];      // block whose sequences header defines the table this block uses (itself unless repeat mode)
+    // repcodes: out = f(in), slot by slot.  kind 0: the constant val; kind 1..3: max(in[kind - 1] - val, 1)  (U/ZstdDecompressBlock.cs:2387-2443)
+    u32 repKind[3], repVal[3];
+    u32 repIn[3];       // the three repcodes at the block's start (block_offsets)
+    u32 err;            // first error found in this block (0 = none)
+};
+
+// One decoded sequence (U/ZstdDecompressBlock.cs:2360-2484) as seq_decode leaves it for the executor.
+struct SeqRec {
+    u32 off;            // the match offset; when tag != 0 the number to subtract from repIn[tag - 1] (floor 1)
+    u32 llTag;          // litLength | tag << 30
+    u32 ml;             // matchLength
+    u32 pos;            // block-relative output position of the sequence's literals
+};
+
+// status words shared by the decoder's kernels and the host
+enum : u32 { kStFrames = 0, kStErr = 1, kStTotalLo = 2, kStTotalHi = 3, kStUsable = 4, kStUnsized = 5, kStBlocks = 6, kStSeqLo = 8, kStSeqHi = 9,
+             kStErrKeyLo = 10, kStErrKeyHi = 11, kStActualLo = 12, kStActualHi = 13, kStWords = 16 };
 
 // error codes: U/ZSTD_ErrorCode.cs
 enum : u32 {

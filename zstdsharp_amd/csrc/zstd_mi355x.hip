@@ -210,10 +210,12 @@ static Resolved resolve_call(const CallParams& p, size_t srcSize, u32 chunkBytes
     // dual-hash finder; greedy and everything above it -> dual-hash + lazy deferral (no lazy2 / binary-tree / optimal parsers)
     r.finder = r.cp.strategy <= kStratFast ? 0u : r.cp.strategy == kStratDfast ? 1u : 2u;
     // ZSTD_fast probes two of every targetLength + 2 positions once a step is set (negative levels; U/ZstdFast.cs:101-103,
-    // 130-136): the tile finder's counterpart is its probing stride, a power of two
+    // 130-136) but falls back to every position right after each match; the tile finder's counterpart is a floor under its
+    // probing stride (a power of two, fixed per 4-16 KiB), set at half the reference's density so that it does not lose more
+    // ratio than the reference's own step does (measured against the oracle at levels -5 and -20 in tests/test_gpu_boundary.py)
     r.minStrideLog = 0;
-    if (r.cp.strategy == kStratFast && r.cp.targetLength > 1) {
-        const u32 gap = (r.cp.targetLength + 2) / 2;
+    if (r.cp.strategy == kStratFast && r.cp.targetLength > 5) {
+        const u32 gap = (r.cp.targetLength + 2) / 4;
         r.minStrideLog = cp_highbit32(gap); if (r.minStrideLog > 4) r.minStrideLog = 4;
     }
     r.rawLiterals = literals_compression_disabled(r.cp) ? 1u : 0u;
