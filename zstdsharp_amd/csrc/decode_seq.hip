@@ -1,0 +1,449 @@
+// decode_seq.hip — sequences of a frame on gfx950, in three stages:
+//
+//   seq_decode      : one wave per compressed block, ALL blocks of all frames at once.  The block's three FSE tables are built by
+//                     the whole wave (ZSTD_buildFSETable, U/ZstdDecompressBlock.cs:1571-1710) from its own sequences header or
+//                     from the earlier block / dictionary that block_link named for a repeat-mode table (:1746-1840); the state
+//                     chain (ZSTD_decodeSequence, :2360-2484) runs on the scalar unit; every lane extracts the fields of its own
+//                     sequence.  Repcodes cannot be resolved yet — they come from the previous block — so they are resolved
+//                     SYMBOLICALLY: every offset is a number, or "the block's starting repcode i, minus d (floor 1)", and the
+//                     block as a whole maps its three starting repcodes to its three ending ones the same way.  Out: one SeqRec
+//                     per sequence (offset, lengths, block-relative output position), the block's regenerated size and transfer.
+//   place_literals  : one wave per block, all blocks at once, after block_offsets has turned sizes into output offsets: raw
+//                     and RLE blocks, the literals of every sequence and the trailing literals go to their final place.
+//   exec_matches    : one wave per frame, blocks in order (the only ordered stage): the matches (ZSTD_execSequence, :2187-2262),
+//                     64 at a time in dependency rounds; then the frame's checksum (U/ZstdDecompress.cs:1186-1208).
+#include "zmi_decode.h"
+
+namespace zmi {
+
+#ifdef ZMI_LZ_STAMPS
+__device__ unsigned long long g_seqStamps[16];
+#define ZMI_SSTAMP(i) do { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } while (0)
+extern "C" void ZSTDMI_debugReadSeqStamps(unsigned long long* out16, int reset)
+{
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_seqStamps), 16 * sizeof(unsigned long long));
+    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_seqStamps), z, sizeof z); }
+}
+#else
+#define ZMI_SSTAMP(i) do { } while (0)
+#endif
+
+// sequences kernel: 10.4 KiB per wave
+struct SeqLds {
+    SeqSym ll[512], ml[512], of[256];
+    s16 norm[64];
+    u16 symbolNext[64];
+    u32 llLog, mlLog, ofLog;
+};
+
+// One table of ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), whole wave; only the NCount header is parsed by one lane.
+// type: 0 predefined, 1 RLE, 2 compressed (repeat mode was resolved to the block that defined the table).  false = corrupt.
+__device__ __forceinline__ bool set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32 type, u32 max, u32 maxLog,
+                                              const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax, u32 lane)
+{
+    switch (type) {
+    case 1: {
+        if (!srcSize) return false;
+        const u32 sym = uniform((u32)src[0]);
+        if (sym > max) return false;
+        if (lane == 0) {
+            SeqSym e = seq_entry(sym, 1, 0, 1, kind); e.nextState = 0; e.nbBits = 0;
+            t[0] = e; *logPtr = 0;
+        }
+        wave_lds_sync();
+        return true; }
+    case 0:
+        if (lane <= defMax) L.norm[lane] = defNorm[lane];
+        wave_lds_sync();
+        build_seq_dtable_wave(t, L.symbolNext, L.norm, defMax, defLog, kind, lane);
+        if (lane == 0) *logPtr = defLog;
+        wave_lds_sync();
+        return true;
+    default: {
+        u32 maxSV = max, tableLog = 0, hs = 0;
+        if (lane == 0) hs = read_ncount(L.norm, &maxSV, &tableLog, src, srcSize);
+        hs = uniform(hs); maxSV = uniform(maxSV); tableLog = uniform(tableLog);
+        if (!hs || tableLog > maxLog) return false;
+        wave_lds_sync();
+        build_seq_dtable_wave(t, L.symbolNext, L.norm, maxSV, tableLog, kind, lane);
+        if (lane == 0) *logPtr = tableLog;
+        wave_lds_sync();
+        return true; }
+    }
+}
+
+// a repcode slot during the symbolic resolution: kind 0 = the constant val; kind 1..3 = max(in[kind - 1] - val, 1)
+struct RepSlot { u32 kind, val; };
+__device__ __forceinline__ RepSlot rep_minus_one(RepSlot s)       // offset = rep0 - 1, 0 -> 1 (U/ZstdDecompressBlock.cs:2421-2433)
+{
+    if (s.kind == 0) { s.val = s.val > 1 ? s.val - 1 : 1u; return s; }
+    s.val += 1; return s;
+}
+
+__global__ __launch_bounds__(64) void seq_decode_kernel(const u8* __restrict__ src, const FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks,
+                                                        u32 nBlocks, SeqRec* __restrict__ recs, u32* __restrict__ status,
+                                                        const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
+{
+    __shared__ SeqLds L;
+    const u32 bi = blockIdx.x, lane = threadIdx.x;
+    if (bi >= nBlocks) return;
+    BlockDesc& B = blocks[bi];
+    if (B.type != 2 || B.nbSeq == 0 || B.err) return;
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
+    const u32 nbSeq = uniform(B.nbSeq), bsz = uniform(B.bsz), litSize = uniform(B.litSize);
+    const u8* const b = src + B.srcOff;
+    u32 err = 0;
+    do {
+        // ---- the three tables, each from the block that defined it (ZSTD_decodeSeqHeaders, :1845-1943) ----
+        bool ok = true;
+#pragma unroll
+        for (u32 t = 0; t < 3 && ok; ++t) {                         // LL, OF, ML
+            const u32 s = uniform(B.tblSrc[t]);
+            const u8* d; u32 avail, mode;
+            if (s == kDictBlock) {                                  // dctx->fseEntropy from the dictionary (U/ZstdDecompress.cs:1956-1990)
+                const u32 o0 = uniform(t == 0 ? di->llOff : t == 1 ? di->ofOff : di->mlOff), o1 = uniform(t == 0 ? di->repOff : t == 1 ? di->mlOff : di->llOff);
+                d = dictFull + o0; avail = o1 - o0; mode = 2;
+            } else {
+                const BlockDesc& S = blocks[s];
+                mode = (uniform(S.modes) >> (6 - 2 * t)) & 3;
+                const u32 o = uniform(S.tblOff[t]);
+                d = src + S.srcOff + o; avail = uniform(S.bsz) - o;
+            }
+            if (t == 0)      ok = set_seq_table(L, L.ll, &L.llLog, mode, 35, 9, d, avail, 0, dLL_defaultNorm, 6, 35, lane);
+            else if (t == 1) ok = set_seq_table(L, L.of, &L.ofLog, mode, 31, 8, d, avail, 1, dOF_defaultNorm, 5, 28, lane);
+            else             ok = set_seq_table(L, L.ml, &L.mlLog, mode, 52, 9, d, avail, 2, dML_defaultNorm, 6, 52, lane);
+            if (!ok) err = s == kDictBlock ? (u32)kErrDictionaryCorrupted : (u32)kErrCorruption;
+        }
+        if (err) break;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+        // ---- sequences (ZSTD_decompressSequences_body, :2668-2763), 64 at a time ----
+        // The state chain (ZSTD_decodeSequence's three FSE updates, :2360-2484) only needs the LENGTHS of the extra-bit fields, so it
+        // runs wave-uniform on the scalar unit and records, per sequence, the three states and the bit position; each lane then
+        // reads the fields of its own sequence.
+        const u32 bitsOff = uniform(B.bitsOff);
+        SBits bd;
+        if (bitsOff >= bsz || !bd.init(b + bitsOff, (s32)(bsz - bitsOff), lane)) { err = kErrCorruption; break; }
+        u32 sLL = bd.read(L.llLog, lane), sOF = bd.read(L.ofLog, lane), sML = bd.read(L.mlLog, lane);
+        RepSlot s0 = { 1, 0 }, s1 = { 2, 0 }, s2 = { 3, 0 };       // the block's starting repcodes, symbolically
+        u32 outBase = 0, litUsed = 0;
+        SeqRec* __restrict__ const rec = recs + B.seqBase;
+        for (u32 base = 0; base < nbSeq; base += 64) {
+            const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
+            u32 recSt = 0; s32 recPos = 0;
+            ZMI_SSTAMP(0);
+            for (u32 k = 0; k < cnt; k++) {
+                // SeqSym = nextState:16 | nbAddBits:8 | nbBits:8 | baseValue:32 ; only the first dword matters here
+                const u32 vLL = *reinterpret_cast<const u32*>(&L.ll[sLL]), vML = *reinterpret_cast<const u32*>(&L.ml[sML]),
+                          vOF = *reinterpret_cast<const u32*>(&L.of[sOF]);
+                const u32 pk = sLL | (sML << 10) | (sOF << 20);
+                recSt = lane == k ? pk : recSt; recPos = lane == k ? bd.pos : recPos;
+                const u32 eLL = uniform(vLL), eML = uniform(vML), eOF = uniform(vOF);
+                const u32 nLL = eLL >> 24, nML = eML >> 24, nOF = eOF >> 24;
+                bd.pos -= (s32)(((eLL >> 16) & 0xFF) + ((eML >> 16) & 0xFF) + ((eOF >> 16) & 0xFF));   // the extra-bit fields
+                // the three state updates read LL, ML, OF bits in that order: one extraction, split afterwards
+                const u32 all = bd.read(nLL + nML + nOF, lane);
+                sLL = (vLL & 0xFFFF) + (all >> (nML + nOF));
+                sML = (vML & 0xFFFF) + ((all >> nOF) & ~(0xFFFFFFFFu << nML));
+                sOF = (vOF & 0xFFFF) + (all & ~(0xFFFFFFFFu << nOF));
+            }
+            ZMI_SSTAMP(1);
+            // ---- every lane: the fields of its own sequence ----
+            const bool have = lane < cnt;
+            u32 ll = 0, ml = 0, off = 1, code = 4;      // code 4 = a real offset; 0..3 = repcode selector
+            if (have) {
+                const SeqSym qLL = L.ll[recSt & 1023], qML = L.ml[(recSt >> 10) & 1023], qOF = L.of[recSt >> 20];
+                s32 p = recPos;
+                const u32 ofv = bd.field(p, qOF.nbAddBits); p -= qOF.nbAddBits;
+                const u32 mlv = bd.field(p, qML.nbAddBits); p -= qML.nbAddBits;
+                const u32 llv = bd.field(p, qLL.nbAddBits);
+                ll = qLL.baseValue + llv; ml = qML.baseValue + mlv;
+                if (qOF.nbAddBits > 1) off = qOF.baseValue + ofv;
+                else code = qOF.baseValue + (qLL.baseValue == 0) + ofv;     // ofv is 0 or the single extra bit
+            }
+            // ---- repcodes, in sequence order (wave-uniform), relative to the block's starting ones ----
+            u32 tag = 0;
+            {
+                const u64 repMask = ballot(have && code != 4);
+                if (!repMask && cnt >= 3) {
+                    s0.kind = 0; s0.val = read_lane(off, cnt - 1); s1.kind = 0; s1.val = read_lane(off, cnt - 2); s2.kind = 0; s2.val = read_lane(off, cnt - 3);
+                } else {
+                    for (u32 k = 0; k < cnt; k++) {
+                        const u32 cd = read_lane(code, k);
+                        if (cd == 4) { const u32 o = read_lane(off, k); s2 = s1; s1 = s0; s0.kind = 0; s0.val = o; }
+                        else {
+                            RepSlot t;
+                            if (cd == 0) t = s0;
+                            else {
+                                t = cd == 1 ? s1 : (cd == 2 ? s2 : rep_minus_one(s0));
+                                if (cd != 1) s2 = s1;
+                                s1 = s0; s0 = t;
+                            }
+                            if (lane == k) { off = t.val; tag = t.kind; }
+                        }
+                    }
+                }
+            }
+            ZMI_SSTAMP(2);
+            const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
+            const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
+            if (totalLit > litSize - litUsed) { err = kErrCorruption; break; }
+            if (totalOut > 0xFFFFFFFFu - outBase - litSize) { err = kErrCorruption; break; }     // (no valid block regenerates 4 GiB)
+            if (have) {
+                SeqRec r; r.off = off; r.llTag = ll | (tag << 30); r.ml = ml; r.pos = outBase + inclOut - ll - ml;
+                rec[base + lane] = r;
+            }
+            outBase += totalOut; litUsed += totalLit;
+            ZMI_SSTAMP(3);
+        }
+        if (err) break;
+        if (bd.pos > 0) { err = kErrCorruption; break; }          // bitstream not fully consumed (:2730-2733)
+        if (lane == 0) {
+            B.outSize = outBase + (litSize - litUsed);
+            B.repKind[0] = s0.kind; B.repVal[0] = s0.val; B.repKind[1] = s1.kind; B.repVal[1] = s1.val; B.repKind[2] = s2.kind; B.repVal[2] = s2.val;
+        }
+    } while (false);
+    if (err && lane == 0) { B.err = err; report_error(status, bi, kStageSequences, err); }
+#ifdef ZMI_LZ_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_seqStamps[i], stampAcc[i]);
+#endif
+}
+
+void launch_seq_decode(const u8* src, const FrameDesc* frames, BlockDesc* blocks, u32 nBlocks, SeqRec* recs, u32* status,
+                       const u8* dictFull, const DictInfo* di, hipStream_t stream)
+{
+    hipLaunchKernelGGL(seq_decode_kernel, dim3(nBlocks), dim3(64), 0, stream, src, frames, blocks, nBlocks, recs, status, dictFull, di);
+}
+
+// ------------------------------------------------------------------------------------------------
+// place_literals: everything that is not a match goes to its final place; one wave per block
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void place_literals_kernel(const u8* __restrict__ src, u8* __restrict__ out, const u8* __restrict__ scratch,
+                                                            const FrameDesc* __restrict__ frames, const BlockDesc* __restrict__ blocks, u32 nBlocks,
+                                                            const SeqRec* __restrict__ recs, const u32* __restrict__ status)
+{
+    const u32 bi = blockIdx.x, lane = threadIdx.x;
+    if (bi >= nBlocks || status[kStErr]) return;
+    const BlockDesc& B = blocks[bi];
+    const FrameDesc& F = frames[B.frame];
+    if (F.bad || B.err) return;
+    u8* __restrict__ const o = out + F.dstOff + B.dstRel;
+    const u32 type = uniform((u32)B.type);
+    if (type == 0) { wave_copy(o, src + B.srcOff, uniform(B.bsz), lane); return; }           // ZSTD_copyRawBlock, U/ZstdDecompress.cs:1004-1027
+    if (type == 1) {                                                                          // ZSTD_setRleBlock, :1029-1052
+        const u32 n = uniform(B.outSize); const u8 v = src[B.srcOff];
+        const u64 v8 = 0x0101010101010101ull * v;
+        for (u32 i = lane * 8; i + 8 <= n; i += 512) *(u64u*)(o + i) = v8;
+        if (lane < (n & 7)) o[(n & ~7u) + lane] = v;
+        return;
+    }
+    const u32 litType = uniform((u32)B.litType), litSize = uniform(B.litSize), nbSeq = uniform(B.nbSeq);
+    if (nbSeq == 0 && litType >= 2) return;                     // decoded in place by the literal decoder
+    const u8* __restrict__ lit = nullptr; u32 rleByte = 0; const bool litIsRle = litType == 1;
+    if (litType >= 2) lit = scratch + F.scratchOff + B.litRel + (u64)B.frame * kLitSkew;
+    else if (litType == 0) lit = src + B.srcOff + B.lhSize;
+    else rleByte = src[B.srcOff + B.lhSize];
+    u32 litPos = 0, outEnd = 0;
+    const SeqRec* __restrict__ const rec = recs + B.seqBase;
+    for (u32 base = 0; base < nbSeq; base += 64) {
+        const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
+        const bool have = lane < cnt;
+        u32 ll = 0, ml = 0, pos = 0;
+        if (have) { const SeqRec r = rec[base + lane]; ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; }
+        const u32 inclLit = wave_scan_incl(ll);
+        const u32 totalLit = read_lane(inclLit, 63);
+        const u32 sLit = litPos + inclLit - ll;
+        outEnd = read_lane(pos + ll + ml, cnt - 1);
+        // literals: short runs by their own lane; long runs are cut into 16-byte pieces (the last one overlapping the one before,
+        // so every piece is whole) and ALL pieces of the batch are dealt to the lanes round-robin, four in flight per lane: the
+        // copy is paced by bandwidth, not by one load-store round trip per run
+        const bool longLit = ll > 32;
+        if (have && !longLit) {
+            if (litIsRle) for (u32 i = 0; i < ll; i++) o[pos + i] = (u8)rleByte;
+            else lane_copy(o + pos, lit + sLit, ll);
+        }
+        if (litIsRle) {
+            u64 lm = ballot(have && longLit);
+            while (lm) {
+                const u32 i = ctz64(lm); lm &= lm - 1;
+                const u32 d0 = read_lane(pos, i), n0 = read_lane(ll, i);
+                for (u32 k2 = lane; k2 < n0; k2 += 64) o[d0 + k2] = (u8)rleByte;
+            }
+        } else if (ballot(have && longLit)) {
+            const u32 pc = (have && longLit) ? (ll + 15) >> 4 : 0;
+            const u32 pIncl = wave_scan_incl(pc), pExcl = pIncl - pc;
+            const u32 P = read_lane(pIncl, 63);
+            for (u32 q0 = 0; q0 < P; q0 += 256) {
+                u64 a[4], b2[4]; u32 dd[4]; bool okp[4];
+#pragma unroll
+                for (u32 t = 0; t < 4; ++t) {
+                    const u32 q = q0 + t * 64 + lane;
+                    okp[t] = q < P;
+                    u32 j = 0;                       // the run that owns piece q: first lane whose inclusive count exceeds q
+#pragma unroll
+                    for (u32 st = 32; st; st >>= 1) { const u32 v = __shfl(pIncl, (int)(j + st - 1)); if (v <= q) j += st; }
+                    const u32 nj = __shfl(ll, (int)j), sj = __shfl(sLit, (int)j), dj = __shfl(pos, (int)j), ej = __shfl(pExcl, (int)j);
+                    u32 oo = 16 * (q - ej); if (oo + 16 > nj) oo = nj - 16;
+                    a[t] = 0; b2[t] = 0; dd[t] = dj + oo;
+                    if (okp[t]) { a[t] = readLE64(lit + sj + oo); b2[t] = readLE64(lit + sj + oo + 8); }
+                }
+#pragma unroll
+                for (u32 t = 0; t < 4; ++t) if (okp[t]) { *(u64u*)(o + dd[t]) = a[t]; *(u64u*)(o + dd[t] + 8) = b2[t]; }
+            }
+        }
+        litPos += totalLit;
+    }
+    {   // trailing literals (:2747-2760); for a block without sequences: all of them
+        const u32 lastLL = litSize - litPos;
+        if (litIsRle) { for (u32 i = lane; i < lastLL; i += 64) o[outEnd + i] = (u8)rleByte; }
+        else wave_copy(o + outEnd, lit + litPos, lastLL, lane);
+    }
+}
+
+void launch_place_literals(const u8* src, u8* out, const u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks,
+                           const SeqRec* recs, const u32* status, hipStream_t stream)
+{
+    hipLaunchKernelGGL(place_literals_kernel, dim3(nBlocks), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, recs, status);
+}
+
+// ------------------------------------------------------------------------------------------------
+// exec_matches: the ordered stage, one wave per frame
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void exec_matches_kernel(const u8* __restrict__ src, u8* __restrict__ out, const FrameDesc* __restrict__ frames,
+                                                          const BlockDesc* __restrict__ blocks, u32 nFrames, const SeqRec* __restrict__ recs,
+                                                          u32* __restrict__ status, const u8* __restrict__ dict, const u32 dictSize)
+{
+    const u32 f = blockIdx.x, lane = threadIdx.x;
+    if (f >= nFrames || status[kStErr]) return;
+    const FrameDesc& F = frames[f];
+    if (F.bad || !(F.hasSeq || F.checksum)) return;
+    u8* const fout = out + F.dstOff;
+    const u32 first = uniform(F.firstBlock), nb = uniform(F.nbBlocks);
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long stampAcc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+#endif
+    u32 err = 0, errBlock = first;
+    for (u32 k = 0; k < nb && !err && F.hasSeq; ++k) {
+        const BlockDesc& B = blocks[first + k];
+        const u32 nbSeq = uniform(B.type == 2 ? B.nbSeq : 0u);
+        if (!nbSeq) continue;
+        const u64 bRel = B.dstRel;                               // frame-relative start of the block's output
+        u8* const o = fout + bRel;
+        const u32 in0 = uniform(B.repIn[0]), in1 = uniform(B.repIn[1]), in2 = uniform(B.repIn[2]);
+        const SeqRec* __restrict__ const rec = recs + B.seqBase;
+        // output of earlier blocks (other waves' literals included: kernel boundary) and of this wave so far is visible
+        for (u32 base = 0; base < nbSeq; base += 64) {
+            const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
+            const bool have = lane < cnt;
+            u32 ll = 0, ml = 0, pos = 0, off = 1;
+            if (have) {
+                const SeqRec r = rec[base + lane];
+                ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; off = r.off;
+                const u32 tag = r.llTag >> 30;
+                if (tag) { const u32 in = tag == 1 ? in0 : tag == 2 ? in1 : in2; off = in > off ? in - off : 1u; }
+            }
+            ZMI_SSTAMP(0);
+            const u32 dMatch = pos + ll;                          // block-relative start of my match
+            // offset beyond everything produced so far in this frame (+ the dictionary): corruption (:2218-2223)
+            if (ballot(have && ((u64)off > bRel + dMatch + dictSize || off == 0))) { err = kErrCorruption; errBlock = first + k; break; }
+            // ---- matches, in dependency rounds ----
+            // A match may start once every earlier match of this batch whose output its source touches is complete (literals and
+            // everything before the batch already are).  Each round runs all matches that are ready: short ones by their own
+            // lane, long ones by the whole wave, then one fence.  The number of rounds is the depth of the dependency chain.
+            u32 dictN = 0;
+            if (dictSize) {                                 // uniform
+                // a match that starts in the dictionary (ZSTD_execSequence's extDict branch, :2223-2250): its first bytes come from
+                // the dictionary's tail (read-only, no dependency), the rest is an ordinary match whose source is the frame's start
+                if (have && (u64)off > bRel + dMatch) {
+                    const u32 back = (u32)((u64)off - (bRel + dMatch));
+                    dictN = back < ml ? back : ml;
+                    const u8* ds = dict + (dictSize - back);
+                    for (u32 i = 0; i < dictN; i++) o[dMatch + i] = ds[i];
+                }
+            }
+            const u32 dMatchR = dMatch + dictN, mlR = ml - dictN;      // what remains for the rounds
+            const bool hasMatch = have && mlR != 0;
+            // block-relative source interval; negative = in earlier blocks (complete)
+            const s64 srcLo = (s64)dMatchR - (s64)off, srcHi = srcLo + (s64)(off < mlR ? off : mlR);
+            // earlier lanes whose match output overlaps my source: outputs are laid out in lane order, so they form a lane
+            // interval [jl, jh) found by two binary searches over the (monotone) per-lane bounds
+            const u64 mm = ballot(hasMatch);
+            const s64 endOutX = have ? (s64)dMatch + ml : (s64)0x7FFFFFFFFFFFll, dMatchX = have ? (s64)dMatch : (s64)0x7FFFFFFFFFFFll;
+            u32 jl = 0, jh = 0;
+#pragma unroll
+            for (u32 st = 32; st; st >>= 1) {
+                const s64 v0 = __shfl(endOutX, (int)(jl + st - 1)), v1 = __shfl(dMatchX, (int)(jh + st - 1));
+                if (v0 <= srcLo) jl += st;
+                if (v1 < srcHi) jh += st;
+            }
+            const u64 dep = (jh > jl ? ((~0ull >> (64 - (jh - jl))) << jl) : 0ull) & mm & lanemask_lt();
+            u64 doneMask = ~mm;                            // lanes without a match never block anyone
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");      // output of earlier batches visible
+            bool mine = hasMatch;
+            ZMI_SSTAMP(1);
+            while (doneMask != ~0ull) {
+                const bool ready = mine && (dep & ~doneMask) == 0;
+                const bool longM = mlR > 64;
+                if (ready && !longM) lane_match_copy(o + dMatchR, off, mlR);
+                u64 lm = ballot(ready && longM);
+                while (lm) {
+                    const u32 i = ctz64(lm); lm &= lm - 1;
+                    wave_match_copy(o + read_lane(dMatchR, i), read_lane(off, i), read_lane(mlR, i), lane);
+                }
+                const u64 r = ballot(ready);
+                doneMask |= r; mine = mine && !ready;
+                if (doneMask != ~0ull) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+#ifdef ZMI_LZ_STAMPS
+                stampAcc[6] += 1;
+#endif
+            }
+#ifdef ZMI_LZ_STAMPS
+            stampAcc[7] += 1;
+#endif
+            ZMI_SSTAMP(2);
+        }
+    }
+#ifdef ZMI_LZ_STAMPS
+    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_seqStamps[8 + i], stampAcc[i]);
+#endif
+    if (err) { if (lane == 0) report_error(status, errBlock, kStageExec, err); return; }
+    if (F.checksum) {
+        // XXH64 of the regenerated frame: accumulators on lanes 0..3 (U/ZstdDecompress.cs:1186-1208)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+        auto rotl = [](u64 x, int r) { return (x << r) | (x >> (64 - r)); };
+        auto rnd = [&](u64 acc, u64 in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
+        const u64 n = F.dstSize, stripes = n >> 5; const u32 j = lane & 3;
+        u64 v = j == 0 ? P1 + P2 : j == 1 ? P2 : j == 2 ? 0 : 0 - P1;
+        if (lane < 4) for (u64 i = 0; i < stripes; i++) v = rnd(v, readLE64(fout + 32 * i + 8 * j));
+        const u64 v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+        u32 bad = 0;
+        if (lane == 0) {
+            u64 hh;
+            if (n >= 32) {
+                hh = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+                auto mrg = [&](u64 acc, u64 x) { acc ^= rnd(0, x); return acc * P1 + P4; };
+                hh = mrg(hh, v1); hh = mrg(hh, v2); hh = mrg(hh, v3); hh = mrg(hh, v4);
+            } else hh = P5;
+            hh += n;
+            const u8* q = fout + (stripes << 5); const u8* const end = fout + n;
+            while (q + 8 <= end) { hh ^= rnd(0, readLE64(q)); hh = rotl(hh, 27) * P1 + P4; q += 8; }
+            if (q + 4 <= end) { hh ^= (u64)readLE32(q) * P1; hh = rotl(hh, 23) * P2 + P3; q += 4; }
+            while (q < end) { hh ^= (*q) * P5; hh = rotl(hh, 11) * P1; q++; }
+            hh ^= hh >> 33; hh *= P2; hh ^= hh >> 29; hh *= P3; hh ^= hh >> 32;
+            if ((u32)hh != readLE32(src + F.srcOff + F.srcSize - 4)) bad = 1;
+        }
+        if (uniform(bad) && lane == 0) report_error(status, (u64)first + nb - 1, kStageFrameEnd, kErrChecksumWrong);
+    }
+}
+
+void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
+                         const u8* dict, u32 dictSize, hipStream_t stream)
+{
+    // dict: a raw-content dictionary (or a formatted one's content) = history in front of EVERY frame (ZSTD_refDictContent,
+    // U/ZstdDecompress.cs:1758-1771); may be null
+    hipLaunchKernelGGL(exec_matches_kernel, dim3(nFrames), dim3(64), 0, stream, src, out, frames, blocks, nFrames, recs, status, dict, dict ? dictSize : 0u);
+}
+
+} // namespace zmi

@@ -14,6 +14,7 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 typedef int16_t  s16;
 typedef int32_t  s32;
+typedef int64_t  s64;
 
 // ---- framing: one independent zstd frame per 64 KiB chunk ----
 constexpr u32 kChunkLog   = 16;
@@ -91,6 +92,8 @@ struct FrameDesc {      // one per frame found by the frame walk (U/ZstdDecompre
     u32 firstBlock, nbBlocks;
     u32 unsized;        // 1 = the header carries no content size
     u32 checksum;       // 1 = a 4-byte XXH64 checksum follows the last block
+    u32 bad;            // 1 = some stage failed in this frame (its error is in the status words): later stages leave it alone
+    u32 hasSeq;         // 1 = at least one block holds sequences (the ordered executor has work in this frame)
 };
 
 constexpr u32 kNoBlock   = 0xFFFFFFFFu;     // table source: nothing defined it (corruption, or the default where that is legal)

@@ -28,17 +28,23 @@ void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* to
 void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
                    u32 nChunks, u32 chunkBytes, hipStream_t stream);
 void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, hipStream_t stream);
-// decoder
+// decoder (decode_walk.hip, decode_lit.hip, decode_seq.hip)
 size_t decode_walk_workspace_bytes(u64 srcSize);
-void launch_frame_walk(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status /*[0]=nFrames [1]=err [2..3]=total [4]=usable*/,
-                       u8* walkWs, hipStream_t stream);
-void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, u32 maxFrames, u32* status, u32 dictID, hipStream_t stream);
+void launch_frame_walk_count(const u8* src, u64 srcSize, u32 maxFrames, u32* status, u8* walkWs, hipStream_t stream);
+void launch_frame_walk_emit(const u8* src, u64 srcSize, FrameDesc* frames, BlockDesc* blocks, u8* walkWs, hipStream_t stream);
+void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, BlockDesc* blocks, u32 maxFrames, u32* status, u32 dictID, u32 emit,
+                              hipStream_t stream);
 void launch_dict_parse(const u8* dict, u32 dictSize, DictInfo* out, hipStream_t stream);
-void launch_decode_literals(const u8* src, u64 srcSize, const FrameDesc* frames, u32 nFrames, u32* frameErr, u8* litScratch, u64 dstCapacity,
+void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32* status, hipStream_t stream);
+void launch_seq_decode(const u8* src, const FrameDesc* frames, BlockDesc* blocks, u32 nBlocks, SeqRec* recs, u32* status,
+                       const u8* dictFull, const DictInfo* di, hipStream_t stream);
+void launch_block_offsets(FrameDesc* frames, BlockDesc* blocks, u32 nFrames, const DictInfo* di, u32 rescan, u64 dstCapacity, u32* status, hipStream_t stream);
+void launch_decode_literals(const u8* src, u8* out, u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks, u32* status,
                             u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream);
-void launch_decode_sequences(const u8* src, u64 srcSize, u8* dst, u64 dstCapacity, const FrameDesc* frames, u32 nFrames, u32* frameErr,
-                             const u8* litScratch, u32* frameActual, const u8* dict, u32 dictSize, const u8* dictFull, const DictInfo* di,
-                             hipStream_t stream);
+void launch_place_literals(const u8* src, u8* out, const u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks,
+                           const SeqRec* recs, const u32* status, hipStream_t stream);
+void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
+                         const u8* dict, u32 dictSize, hipStream_t stream);
 }
 
 using namespace zmi;
@@ -144,7 +150,7 @@ struct ZSTD_DCtx_s {
     int windowLogMax = 27;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf frames, status, frameErr, scratch, walkWs, slowFlags, stageSrc, stageDst, actual;
+    DevBuf frames, blocks, recs, status, scratch, walkWs, slowFlags, stageSrc, stageDst;
     StageTimer timer;
     // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
     std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
@@ -510,7 +516,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->status.release(); d->frameErr.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->actual.release(); d->dict.release(); d->dictInfoDev.release();
+        d->frames.release(); d->blocks.release(); d->recs.release(); d->status.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->dict.release(); d->dictInfoDev.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -680,15 +686,18 @@ static size_t dctx_sync_dictionary(ZSTD_DCtx* d)
     return 0;
 }
 
+// The decompress pipeline over device-resident buffers.  Two host round trips size the work lists (frames + blocks after the
+// counting walk, sequence records after the block pre-pass); everything else is one launch sequence:
+//   walk (count) | walk (emit) -> block_parse -> block_link -> seq_scan | seq_decode -> block_offsets [-> frame_rescan]
+//   -> decode_literals -> place_literals -> exec_matches
 static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
 {
     hipStream_t s = d->stream;
     if (srcSize == 0) return 0;
     // a frame is at least 9 bytes; our own streams hold one per 64 KiB, foreign ones usually far fewer
-    const u32 maxFrames = (u32)((srcSize / 9 + 1) < (1u << 22) ? (srcSize / 9 + 1) : (1u << 22));
-    if (!d->frames.ensure((size_t)maxFrames * sizeof(FrameDesc)) || !d->status.ensure(64) || !d->walkWs.ensure(decode_walk_workspace_bytes(srcSize)))
-        return ZERR(kErrMemoryAllocation);
-    FrameDesc* frames = (FrameDesc*)d->frames.p; u32* status = (u32*)d->status.p;
+    const u32 maxFrames = (u32)((srcSize / 9 + 1) < (1u << 26) ? (srcSize / 9 + 1) : (1u << 26));
+    if (!d->status.ensure(kStWords * sizeof(u32)) || !d->walkWs.ensure(decode_walk_workspace_bytes(srcSize))) return ZERR(kErrMemoryAllocation);
+    u32* status = (u32*)d->status.p;
     { const size_t e = dctx_sync_dictionary(d); if (isErr(e)) return e; }
     const bool fmt = d->dictFormatted && !d->dictHost.empty();
     const u8* const dictFull = fmt ? (const u8*)d->dict.p : nullptr;
@@ -696,51 +705,52 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     const u8* const dictContent = d->dictHost.empty() ? nullptr : (const u8*)d->dict.p + (fmt ? d->info.contentOff : 0u);
     const u32 dictContentSize = d->dictHost.empty() ? 0u : (fmt ? d->info.contentSize : (u32)d->dictHost.size());
     const u32 dictID = fmt ? d->info.dictID : 0u;
+    auto read_status = [&](u32* st) -> bool {
+        if (hipMemcpyAsync(st, status, kStWords * sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return false;
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return false; }
+        return true;
+    };
     d->timer.begin(s);
-    launch_frame_walk(d_src, srcSize, frames, maxFrames, status, (u8*)d->walkWs.p, s);       d->timer.mark("frame_walk", s);
-    u32 st[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
-    if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
-    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-    const bool serialWalk = !st[4];
+    {   // error key = "none" (all ones); everything else zero
+        u32 init[kStWords] = {}; init[kStErrKeyLo] = 0xFFFFFFFFu; init[kStErrKeyHi] = 0xFFFFFFFFu;
+        if (hipMemcpyAsync(status, init, sizeof init, hipMemcpyHostToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
+    }
+    u32 st[kStWords] = {};
+    launch_frame_walk_count(d_src, srcSize, maxFrames, status, (u8*)d->walkWs.p, s);
+    if (!read_status(st)) return ZERR(kErrGeneric);
+    const bool serialWalk = !st[kStUsable];
     if (serialWalk) {   // the segment links did not close: take the exact serial walk (it also yields the reference's error code)
-        launch_frame_walk_serial(d_src, srcSize, frames, maxFrames, status, dictID, s);
-        if (hipMemcpyAsync(st, status, sizeof st, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
-        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        launch_frame_walk_serial(d_src, srcSize, nullptr, nullptr, maxFrames, status, dictID, 0, s);
+        if (!read_status(st)) return ZERR(kErrGeneric);
     }
-    if (st[1]) return ZERR(st[1]);
-    const u32 nFrames = st[0];
-    const u64 total = (u64)st[2] | ((u64)st[3] << 32);
-    if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
+    if (st[kStErr]) return ZERR(st[kStErr]);
+    const u32 nFrames = st[kStFrames], nBlocks = st[kStBlocks], nUnsized = st[kStUnsized];
+    const u64 total = (u64)st[kStTotalLo] | ((u64)st[kStTotalHi] << 32);       // content sizes (bounds for frames without one)
+    if (!nUnsized && total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
     if (nFrames == 0) { d->timer.finish(); return 0; }
-    if (!d->frameErr.ensure(64) || !d->scratch.ensure((size_t)total + (size_t)nFrames * kLitSkew + 256) || !d->slowFlags.ensure((size_t)nFrames + 64)) return ZERR(kErrMemoryAllocation);
-    (void)hipMemsetAsync(d->frameErr.p, 0, 64, s);
-    launch_decode_literals(d_src, srcSize, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, total, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s);     d->timer.mark("decode_literals", s);
-    // frames without a content size (st[5] of them; only the serial walk lets them through) are decoded into bound-sized
-    // slots, report their regenerated size, and are then moved down to close the gaps
-    const u32 nUnsized = serialWalk ? st[5] : 0u;
-    if (nUnsized && !d->actual.ensure((size_t)nFrames * sizeof(u32))) return ZERR(kErrMemoryAllocation);
-    launch_decode_sequences(d_src, srcSize, d_dst, total, frames, nFrames, (u32*)d->frameErr.p, (u8*)d->scratch.p, nUnsized ? (u32*)d->actual.p : nullptr,
-                            dictContent, dictContentSize, dictFull, dinfo, s);   d->timer.mark("decode_sequences", s);
-    u32 err = 0;
-    if (hipMemcpyAsync(&err, d->frameErr.p, sizeof err, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
-    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    if (!d->frames.ensure((size_t)nFrames * sizeof(FrameDesc)) || !d->blocks.ensure((size_t)nBlocks * sizeof(BlockDesc) + 64) ||
+        !d->scratch.ensure((size_t)total + (size_t)nFrames * kLitSkew + 256) || !d->slowFlags.ensure((size_t)nBlocks + 64)) return ZERR(kErrMemoryAllocation);
+    FrameDesc* frames = (FrameDesc*)d->frames.p; BlockDesc* blocks = (BlockDesc*)d->blocks.p;
+    if (serialWalk) launch_frame_walk_serial(d_src, srcSize, frames, blocks, maxFrames, status, dictID, 1, s);
+    else            launch_frame_walk_emit(d_src, srcSize, frames, blocks, (u8*)d->walkWs.p, s);
+    d->timer.mark("frame_walk", s);
+    launch_block_prepass(d_src, frames, blocks, nFrames, nBlocks, fmt ? 1u : 0u, status, s);
+    if (!read_status(st)) return ZERR(kErrGeneric);
+    d->timer.mark("block_prepass", s);
+    const u64 nSeq = (u64)st[kStSeqLo] | ((u64)st[kStSeqHi] << 32);
+    if (!d->recs.ensure((size_t)(nSeq + 64) * sizeof(SeqRec))) return ZERR(kErrMemoryAllocation);
+    SeqRec* recs = (SeqRec*)d->recs.p;
+    launch_seq_decode(d_src, frames, blocks, nBlocks, recs, status, dictFull, dinfo, s);            d->timer.mark("seq_decode", s);
+    launch_block_offsets(frames, blocks, nFrames, dinfo, nUnsized ? 1u : 0u, dstCapacity, status, s);  d->timer.mark("block_offsets", s);
+    launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s);
+    d->timer.mark("decode_literals", s);
+    launch_place_literals(d_src, d_dst, (const u8*)d->scratch.p, frames, blocks, nBlocks, recs, status, s);    d->timer.mark("place_literals", s);
+    launch_exec_matches(d_src, d_dst, frames, blocks, nFrames, recs, status, dictContent, dictContentSize, s);  d->timer.mark("exec_matches", s);
+    if (!read_status(st)) return ZERR(kErrGeneric);
     d->timer.finish();
-    if (err) return ZERR(err);
-    if (nUnsized) {
-        std::vector<FrameDesc> hf(nFrames); std::vector<u32> ha(nFrames);
-        if (hipMemcpy(hf.data(), frames, (size_t)nFrames * sizeof(FrameDesc), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
-        if (hipMemcpy(ha.data(), d->actual.p, (size_t)nFrames * sizeof(u32), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
-        u64 at = 0;
-        for (u32 f = 0; f < nFrames; ++f) {
-            if (at != hf[f].dstOff && ha[f]) {      // overlapping move: through the literal scratch (it is as large as the output)
-                if (hipMemcpyAsync(d->scratch.p, d_dst + hf[f].dstOff, ha[f], hipMemcpyDeviceToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
-                if (hipMemcpyAsync(d_dst + at, d->scratch.p, ha[f], hipMemcpyDeviceToDevice, s) != hipSuccess) return ZERR(kErrGeneric);
-            }
-            at += ha[f];
-        }
-        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-        return (size_t)at;
-    }
+    if (st[kStErrKeyLo] != 0xFFFFFFFFu || st[kStErrKeyHi] != 0xFFFFFFFFu) return ZERR(st[kStErrKeyLo] & 0xFFFFu);   // the first failing block's first error
+    if (st[kStErr]) return ZERR(st[kStErr]);                  // regenerated sizes of unsized frames exceed the destination
+    if (nUnsized) return (size_t)((u64)st[kStActualLo] | ((u64)st[kStActualHi] << 32));
     return (size_t)total;
 }
 
