@@ -44,10 +44,12 @@ def make_zipf(n, seed, device):
     return out
 
 
-STAGE_KERNEL = {"compress/lz_fast": "lz_kernel", "compress/huf_build": "huf_build_kernel", "compress/huf_encode": "huf_encode_kernel",
+STAGE_KERNEL = {"compress/lz_fast": "lz_kernel", "compress/huf_build": "huf_hist_kernel", "compress/huf_encode": "huf_encode_kernel",
                 "compress/seq_encode": "seq_encode_kernel", "compress/gather": "gather_kernel",
                 "decompress/decode_literals": ("decode_literals_compact_kernel", "decode_literals_kernel", "decode_literals_sync_kernel"),
-                "decompress/decode_sequences": "decode_sequences_kernel"}
+                "decompress/seq_decode": "seq_decode_kernel", "decompress/place_literals": "place_literals_kernel",
+                "decompress/exec_matches": "exec_matches_kernel", "decompress/frame_walk": "walk_segments_kernel",
+                "decompress/block_prepass": "block_parse_kernel", "decompress/block_offsets": "block_offsets_kernel"}
 
 
 def pmc_traffic(stage, size_mib, kind, level):
@@ -84,12 +86,24 @@ def stage_times(lib, ctx, getter):
     return {names[i].decode(): float(ms[i]) for i in range(n)}
 
 
-def cpu_baseline(sample: bytes, threads: int):
-    """The oracle (a plain-C port of the reference's level-1 path), same 64 KiB framing, on the host cores."""
+def oracle_frames(data: bytes, level: int, frame_bytes: int, threads: int) -> bytes:
+    """`data` as independent zstd frames of frame_bytes each, built by the oracle (= the reference's algorithm at that level:
+    128 KiB blocks, history and repeat-mode tables across the blocks of a frame) on `threads` host threads (ctypes drops the GIL)."""
+    import oracle_lib as o
+    from concurrent.futures import ThreadPoolExecutor
+    pieces = [data[i:i + frame_bytes] for i in range(0, len(data), frame_bytes)]
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        out = list(ex.map(lambda b: o.compress(b, level, 0, 0), pieces))
+    assert all(not isinstance(b, int) for b in out), "the oracle refused a frame"
+    return b"".join(out)
+
+
+def cpu_baseline(sample: bytes, threads: int, level: int = 1):
+    """The oracle (a plain-C port of the reference's path at `level`), same 64 KiB framing, on the host cores."""
     import oracle_lib as o
     n = len(sample)
     t0 = time.perf_counter()
-    comp = o.compress(sample, 1, 0, 65536)
+    comp = o.compress(sample, level, 0, 65536)
     t1 = time.perf_counter()
     back = o.decompress(comp, n)
     t2 = time.perf_counter()
@@ -100,11 +114,107 @@ def cpu_baseline(sample: bytes, threads: int):
         per = (n // threads) // 65536 * 65536
         parts = [sample[i * per:(i + 1) * per] for i in range(threads)]
         def work(b):
-            c = o.compress(b, 1, 0, 65536); assert o.decompress(c, len(b)) == b
+            c = o.compress(b, level, 0, 65536); assert o.decompress(c, len(b)) == b
         ths = [threading.Thread(target=work, args=(b,)) for b in parts]
         t0 = time.perf_counter(); [t.start() for t in ths]; [t.join() for t in ths]; t1 = time.perf_counter()
         allc = dict(roundtrip=per * threads / (t1 - t0) / 1e6, cores=threads)
     return one, allc
+
+
+def run_decompress(args, lib, z, torch, dist, dev, rank, world, local, make_input):
+    """BASELINE configs[4]: decompress-only of pre-built frames.  The frames are built ONCE, outside the timed region: by the
+    oracle (reference-shaped: one frame per --frame-mib of input, 128 KiB blocks chained by history, repcodes and repeat-mode
+    tables) or by the GPU compressor (64 KiB single-block frames).  A step = one ZSTDMI_decompressDevice call over all of them,
+    compressed input and output resident in HBM; value = regenerated bytes of all ranks / step time."""
+    import numpy as np
+    n = args.size_mib << 20
+    unique = min(args.unique_mib << 20, n)
+    frame_bytes = int(args.frame_mib * (1 << 20))
+    threads = max(1, min(16, len(os.sched_getaffinity(0))))
+    usrc, what = make_input(unique, 7 + rank)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if args.frames == "oracle":
+        blob = oracle_frames(usrc.cpu().numpy().tobytes(), args.level, frame_bytes, threads)
+        comp_u = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).to(dev)
+        framing = f"oracle-built level-{args.level} frames of {args.frame_mib:g} MiB ({(frame_bytes + 131071) // 131072} blocks each)"
+    else:
+        cap = lib.ZSTD_compressBound(unique)
+        tmp = torch.empty(cap, dtype=torch.uint8, device=dev)
+        with z.Compressor(args.level, device=local) as c:
+            cs = lib.ZSTDMI_compressDevice(c.cctx, tmp.data_ptr(), cap, usrc.data_ptr(), unique)
+        assert cs < (1 << 63), lib.ZSTD_getErrorName(cs)
+        comp_u = tmp[:cs].clone(); del tmp
+        framing = f"GPU-built level-{args.level} frames, one per 64 KiB chunk"
+    build_s = time.perf_counter() - t0
+    reps = max(1, n // unique); n = reps * unique
+    comp = comp_u.repeat(reps); want = usrc.repeat(reps)
+    csize = comp.numel()
+    back = torch.empty(n, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    d = z.Decompressor(device=local)
+    lib.ZSTDMI_DCtx_setProfiling(d.dctx, 1)
+
+    def step():
+        r = lib.ZSTDMI_decompressDevice(d.dctx, back.data_ptr(), n, comp.data_ptr(), csize)
+        assert r == n, lib.ZSTD_getErrorName(r)
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier(); torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    sync()
+    acc = {}
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        for k, v in stage_times(lib, d.dctx, lib.ZSTDMI_DCtx_getStageTimes).items(): acc[k] = acc.get(k, 0.0) + v
+    sync()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed = float(t.item())
+    ok = bool(torch.equal(want, back))
+    if dist is not None:
+        t = torch.tensor([1 if ok else 0], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok = bool(t.item())
+    if rank == 0:
+        K = args.steps
+        ratio = csize / n
+        dec_ms = {"decompress/" + k: v / K for k, v in acc.items()}
+        dom = max(dec_ms, key=dec_ms.get)
+        alg_bytes = (1.0 + ratio) * n
+        achieved = alg_bytes / (dec_ms[dom] * 1e-3) / 1e9
+        line = {
+            "metric": f"MB/s decompress, level-{args.level} frames", "value": round(world * n / (elapsed / K) / 1e6, 1) if ok else None, "unit": "MB/s",
+            "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(elapsed / K * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"decompress-only: {n >> 20} MiB of {what} per GPU as {framing}; {unique >> 20} MiB distinct, repeated x{reps}",
+                       "frames": n // frame_bytes if args.frames == "oracle" else (n + 65535) // 65536, "frame_build_s": round(build_s, 1),
+                       "parallelism": f"replicas x{world} (no collective: frames are independent)"},
+            "round_trip_bit_exact": ok, "ratio": round(ratio, 5),
+            "decompress_MBps_per_gpu": round(n / (sum(dec_ms.values()) * 1e-3) / 1e6, 1),
+            "stage_ms": {k: round(v, 4) for k, v in dec_ms.items()},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": None, "algorithmic_GB_per_launch": round(alg_bytes / 1e9, 4)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            import oracle_lib as o
+            m = min(args.cpu_sample_mib << 20, unique) // frame_bytes * frame_bytes if args.frames == "oracle" else min(args.cpu_sample_mib << 20, unique)
+            blob_s = oracle_frames(usrc[:m].cpu().numpy().tobytes(), args.level, frame_bytes, threads) if args.frames == "oracle" \
+                else comp_u.cpu().numpy().tobytes()
+            m = m if args.frames == "oracle" else unique
+            t0 = time.perf_counter(); outb = o.decompress(blob_s, m); t1 = time.perf_counter()
+            assert not isinstance(outb, int) and len(outb) == m
+            line["cpu_baseline"] = {"value": round(m / (t1 - t0) / 1e6, 1), "unit": "MB/s", "cores": 1, "kind": "port",
+                                    "sample": f"{m >> 20} MiB of the same frames decoded by oracle/ (C port of the reference's decoder)"}
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier(); dist.destroy_process_group()
+    d.Dispose()
+    if not ok:
+        sys.exit(1)
 
 
 def main():
@@ -113,7 +223,14 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--size-mib", type=int, default=1024, help="uncompressed bytes per GPU (MiB)")
-    ap.add_argument("--input", default="zipf", choices=["zipf", "text"])
+    ap.add_argument("--input", default="zipf", choices=["zipf", "text", "mixed"],
+                    help="zipf: BASELINE configs[1]; text: stand-in for Silesia dickens; mixed: stand-in for the concatenated Silesia corpus (configs[2])")
+    ap.add_argument("--mode", default="roundtrip", choices=["roundtrip", "decompress"],
+                    help="roundtrip: the metric (compress + decompress per step); decompress: BASELINE configs[4], pre-built frames, decode only")
+    ap.add_argument("--frames", default="oracle", choices=["oracle", "gpu"],
+                    help="--mode decompress: who builds the frames (outside the timed region): the oracle = reference-shaped multi-block frames, or the GPU compressor")
+    ap.add_argument("--frame-mib", type=float, default=1.0, help="--mode decompress --frames oracle: uncompressed bytes per frame (MiB)")
+    ap.add_argument("--unique-mib", type=int, default=256, help="--mode decompress: distinct input the frames are built from (repeated up to --size-mib)")
     ap.add_argument("--level", type=int, default=1, help="compression level (BASELINE.json metric: 1; configs[3] uses 5)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather-v of compressed shards")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
@@ -139,13 +256,24 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
 
     n = args.size_mib << 20
-    if args.input == "zipf":
-        src = make_zipf(n, 1234 + rank, dev); workload = f"{args.size_mib} MiB Zipf(alpha=1.1) bytes per GPU, level {args.level}, 64 KiB independent chunks"
-    else:
+
+    def make_input(nbytes, seed):
         import datagen, numpy as np
-        base = datagen.text_like(64 << 20, 7 + rank)
-        src = torch.from_numpy(np.tile(base, (n + len(base) - 1) // len(base))[:n].copy()).to(dev)
-        workload = f"{args.size_mib} MiB synthetic text (declared stand-in for Silesia dickens, absent offline), level {args.level}, 64 KiB chunks"
+        if args.input == "zipf":
+            return make_zipf(nbytes, seed, dev), "Zipf(alpha=1.1) bytes"
+        if args.input == "text":
+            base = datagen.text_like(min(64 << 20, nbytes), seed)
+            what = "synthetic text (declared stand-in for Silesia dickens, absent offline)"
+        else:
+            base = np.frombuffer(datagen.gen("mixed", min(64 << 20, nbytes), seed), dtype=np.uint8)
+            what = "synthetic mixed corpus: text, Zipf bytes, runs, random, periodic (declared stand-in for the concatenated Silesia corpus, absent offline)"
+        return torch.from_numpy(np.tile(base, (nbytes + len(base) - 1) // len(base))[:nbytes].copy()).to(dev), what
+
+    if args.mode == "decompress":
+        run_decompress(args, lib, z, torch, dist, dev, rank, world, local, make_input)
+        return
+    src, what = make_input(n, (1234 if args.input == "zipf" else 7) + rank)
+    workload = f"{args.size_mib} MiB {what} per GPU, level {args.level}, 64 KiB independent chunks"
     torch.cuda.synchronize()          # the library runs on its own stream: the input must be complete before the first call
     cap = lib.ZSTD_compressBound(n)
     dst = torch.empty(cap + 8192, dtype=torch.uint8, device=dev)      # slack: the gather pads a shard up to a multiple of 4096
@@ -242,9 +370,9 @@ def main():
             m = min(args.cpu_sample_mib << 20, n)
             sample = src[:m].cpu().numpy().tobytes()
             threads = max(1, min(16, len(os.sched_getaffinity(0))))
-            one, allc = cpu_baseline(sample, threads)
+            one, allc = cpu_baseline(sample, threads, args.level)
             line["cpu_baseline"] = {"value": round(one["roundtrip"], 1), "unit": "MB/s", "cores": 1, "kind": "port",
-                                    "sample": f"first {m >> 20} MiB of the same buffer, oracle/ (C port of the reference's level-1 path), 64 KiB frames",
+                                    "sample": f"first {m >> 20} MiB of the same buffer, oracle/ (C port of the reference's level-{args.level} path), 64 KiB frames",
                                     "compress_MBps": round(one["compress"], 1), "decompress_MBps": round(one["decompress"], 1), "ratio": round(one["ratio"], 5),
                                     "all_cores": ({"value": round(allc["roundtrip"], 1), "cores": allc["cores"]} if allc else None)}
         print(json.dumps(line), flush=True)

@@ -378,16 +378,27 @@ def test_frames_without_content_size(gpu_lib, oracle, forced_decoder):
         assert gpu_lib.ZSTD_getFrameContentSize(unsized, len(unsized)) == (1 << 64) - 1      # ZSTD_CONTENTSIZE_UNKNOWN
         bound = gpu_lib.ZSTD_decompressBound(unsized, len(unsized))
         assert n <= bound < (1 << 62)
-        # (Unwrap(src) alone insists on bound == size, as S/Decompressor.cs:56-72 does; the dest form returns the size)
         dest = bytearray(bound)
         assert d.Unwrap(unsized, dest) == n and bytes(dest[:n]) == data
+        # Unwrap(src) sizes its buffer with the bound and returns the regenerated bytes (S/Decompressor.cs:63-75)
+        assert d.Unwrap(unsized) == data
+        # a destination of exactly the regenerated size is enough (ZSTD_decompressDCtx fails only if the bytes really overflow);
+        # one byte less is dstSize_tooSmall, softly through TryUnwrap
+        exact = bytearray(n)
+        assert d.Unwrap(unsized, exact) == n and bytes(exact) == data
+        with pytest.raises(ZstdException) as e:
+            d.Unwrap(unsized, bytearray(n - 1))
+        assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_dstSize_tooSmall
+        assert d.TryUnwrap(unsized, bytearray(n - 1)) == (False, 0)
         blobs.append(unsized); want += data
-    # several unsized frames and a sized one in one buffer: gaps between the bound-sized slots are closed
+    # several unsized frames and a sized one in one buffer: every frame lands right behind the regenerated bytes of the one before
     sized_tail = oracle.compress(b"tail" * 1000, 1, 0, 0)
     both = b"".join(blobs) + sized_tail
     dest = bytearray(gpu_lib.ZSTD_decompressBound(both, len(both)))
     got = d.Unwrap(both, dest)
     assert bytes(dest[:got]) == want + b"tail" * 1000
+    tight = bytearray(len(want) + 4000)
+    assert d.Unwrap(both, tight) == len(tight) and bytes(tight) == want + b"tail" * 1000
     # and through the streaming adapter
     import io
     from zstdsharp_amd.streams import DecompressionStream
@@ -439,10 +450,69 @@ def test_corrupted_frames_fail_cleanly(gpu_lib, oracle, forced_decoder):
     assert errors > 100 and agree > 0 and lenient == 0, (errors, agree, lenient)
 
 
+def test_reference_shaped_frames_decode_block_parallel_at_size(gpu_lib, oracle):
+    """BASELINE configs[4] at full per-launch shape: 1 GiB of level-5 frames as the reference's own Compressor emits them (1 MiB
+    per frame = 8 chained 128 KiB blocks: history, repcodes, repeat-mode tables and treeless literals cross the blocks), decoded
+    with compressed input and output resident in HBM.  64 MiB distinct (oracle-built here), repeated 16 times; bit-exact against
+    the input, plus a checksum-of-checksums property: every frame carries an XXH64 the decoder verifies on the device."""
+    import torch
+    from concurrent.futures import ThreadPoolExecutor
+    unique, reps, fb = 64 << 20, 16, 1 << 20
+    data = datagen.gen("mixed", unique, 77)
+    with ThreadPoolExecutor(max_workers=16) as ex:
+        frames = list(ex.map(lambda i: oracle.compress(data[i:i + fb], 5, 1, 0), range(0, unique, fb)))
+    blob = b"".join(frames)
+    multi = sum(1 for f in frames if f[4] >> 6 == 2)            # 4-byte content size = a frame above 64 KiB: several blocks
+    assert multi == len(frames)
+    comp = torch.from_numpy(np.frombuffer(blob, dtype=np.uint8).copy()).cuda().repeat(reps)
+    want = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda().repeat(reps)
+    out = torch.empty(unique * reps, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with z.Decompressor() as d:
+        r = gpu_lib.ZSTDMI_decompressDevice(d.dctx, out.data_ptr(), out.numel(), comp.data_ptr(), comp.numel())
+        assert r == unique * reps, gpu_lib.ZSTD_getErrorName(r)
+        assert torch.equal(out, want)
+        # one flipped payload byte in the LAST frame: that frame's checksum (or a validation before it) must catch it
+        bad = comp.clone(); bad[comp.numel() - 50] ^= 0x5A
+        r = gpu_lib.ZSTDMI_decompressDevice(d.dctx, out.data_ptr(), out.numel(), bad.data_ptr(), bad.numel())
+        assert r > (1 << 63)
+        # a destination one byte short is dstSize_tooSmall before anything is written
+        r = gpu_lib.ZSTDMI_decompressDevice(d.dctx, out.data_ptr(), out.numel() - 1, comp.data_ptr(), comp.numel())
+        assert r == (1 << 64) - 70
+
+
+def test_level5_compress_at_size(gpu_lib, oracle):
+    """BASELINE configs[2] at full per-launch shape: 1 GiB (mixed corpus stand-in, 64 MiB distinct x 16) compressed at level 5 with
+    input and output resident in HBM; GPU decode restores it, and a 4 MiB slice of the output decodes under the oracle."""
+    import torch
+    unique, reps = 64 << 20, 16
+    n = unique * reps
+    data = datagen.gen("mixed", unique, 78)
+    src = torch.from_numpy(np.frombuffer(data, dtype=np.uint8).copy()).cuda().repeat(reps)
+    cap = gpu_lib.ZSTD_compressBound(n)
+    dst = torch.empty(cap, dtype=torch.uint8, device="cuda"); out = torch.empty(n, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    with z.Compressor(5) as c, z.Decompressor() as d:
+        cs = gpu_lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), n)
+        assert cs < (1 << 63), gpu_lib.ZSTD_getErrorName(cs)
+        cs1 = gpu_lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), unique)      # the first 64 MiB alone: same frames
+        head = dst[:cs1].cpu().numpy().tobytes()
+        cs = gpu_lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), n)
+        assert dst[:cs1].cpu().numpy().tobytes() == head, "chunks are independent: a prefix of the input gives a prefix of the output"
+        assert gpu_lib.ZSTDMI_decompressDevice(d.dctx, out.data_ptr(), n, dst.data_ptr(), cs) == n
+        assert torch.equal(out, src)
+        assert cs < 0.47 * n
+    k = gpu_lib.ZSTD_findFrameCompressedSize(head, len(head))
+    end = 0
+    for _ in range(64):                                              # the first 64 frames = 4 MiB
+        end += gpu_lib.ZSTD_findFrameCompressedSize(head[end:], len(head) - end)
+    assert k > 0 and oracle.decompress(head[:end], 4 << 20) == data[:4 << 20]
+
+
 def test_decode_prebuilt_level5_frames_at_size(gpu_lib, oracle):
     """BASELINE configs[4] at reduced size: decompress-only of pre-built level-5 frames (built by the oracle = the
     reference's level-5 algorithm), bit-exact check.  Both framings: independent 64 KiB frames, and one long multi-block
-    frame with history across blocks (decoded by a single wave: correctness, not speed)."""
+    frame with history across blocks (its blocks decode in parallel; only the match execution walks them in order)."""
     data = datagen.gen("mixed", 24 << 20, 55)
     with z.Decompressor() as d:
         chunked = oracle.compress(data, 5, 1, 65536)
