@@ -203,6 +203,150 @@ __global__ __launch_bounds__(64) void decode_literals_slow_kernel(const u8* __re
 }
 
 // ------------------------------------------------------------------------------------------------
+// One stream on one lane, the form both quad decoders use (HUF_decodeStreamX1, U/HufDecompress.cs:264-309).
+//
+// What bounds a lane is the dependent chain from one symbol's table entry to the next symbol's table index, so that chain is
+// kept to three vector instructions around the LDS read:
+//     t = w >> (31 - IDX)          the index bits (and the bit behind them) of the 32-bit window w
+//     a = (t & mask) | tableBase   LDS address
+//     e = lds[a]                   entry: low 5 bits = 32 - nbBits, bit 5 = "pair", high byte = symbol (or pair number)
+//     w = alignbit(w, r, e)        v_alignbit_b32 takes its shift from the entry's low 5 bits as they are: {w, r} >> (32 - nbBits)
+// (r, q), the 64 bits behind the window, the output packing and the bit count follow off the chain.  After 8 symbols (at most
+// 88 of the 96 bits) the window is rebuilt from the byte stream, see the function body.
+// IDX = index bits of the table (tables of a smaller tableLog are replicated up to it).  PAIRS: tableLog = IDX + 1 is held in the
+// same table: the longest codes come in pairs sharing an IDX-bit prefix; their entry carries the pair's number and the symbol is
+// sorted[2 * pair + next bit] (sorted = symbols in (weight, symbol) order: its head is the pair list) — off the chain.
+// ------------------------------------------------------------------------------------------------
+constexpr u32 kEntPair = 0x20u;
+__device__ __forceinline__ u32 huf_entry(u32 sym, u32 nbBits) { return (32u - nbBits) | (sym << 8); }
+
+#ifndef ZMI_LIT_EXPERIMENT
+#define ZMI_LIT_EXPERIMENT 0            /* timing-only diagnostic builds (tools/lit_experiments.py): 1 no table lookup, 2 no stream loads, 3 no stores */
+#endif
+
+template <u32 IDX, bool PAIRS>
+__device__ __forceinline__ bool huf_decode_stream_fs(const u16* __restrict__ table, const u8* __restrict__ sorted,
+                                                     const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
+{
+    if (srcSize < 1) return false;
+    s32 remaining; u32 i = 0;
+    const u8* const tb = reinterpret_cast<const u8*>(table);
+    constexpr u32 kMask = ((1u << IDX) - 1u) << 1;
+    // one symbol out of the 96-bit window (w, r, q): returns it, advances the window, adds its bits to `used`
+    auto sym1 = [&](u32& w, u32& r, u32& q, u32& used) -> u32 {
+        const u32 t = w >> (31 - IDX);
+#if ZMI_LIT_EXPERIMENT == 1
+        const u32 e = 26u | ((t & 0xFFu) << 8);
+#else
+        const u32 e = *reinterpret_cast<const u16*>(tb + (t & kMask));
+#endif
+        w = __builtin_amdgcn_alignbit(w, r, e);
+        r = __builtin_amdgcn_alignbit(r, q, e);
+        const u32 nb = (0u - e) & 31u;
+        q <<= nb; used += nb;
+        u32 sym = e >> 8;
+        if (PAIRS) { const u32 ps = sorted[(((e >> 8) << 1) | (t & 1u)) & 0xFFu]; sym = (e & kEntPair) ? ps : sym; }    // (pair numbers are < 128; the mask keeps other entries' reads inside `sorted`)
+        return sym;
+    };
+    if (srcSize >= 16) {
+        // The stream is read from its last byte down.  cont = stream bytes [ptr, ptr + 8); (lowHi, lowLo) = the 16 bytes below it,
+        // [ptr - 8, ptr) and [ptr - 16, ptr - 8), loaded one step (8 symbols) ahead of their use; bytes below the stream's start
+        // read as zero.  A step decodes 8 symbols (at most 88 bits) out of the 96 bits behind the `consumed` (<= 8) bits already
+        // used of cont, then re-bases the registers by the whole bytes consumed (<= 12) — from registers, so that the next step
+        // starts at once — and issues the load that replaces (lowHi, lowLo) by the exact 16 bytes below the new cont.  The load
+        // has 8 symbols' time to arrive (an L2 hit takes about 4 symbols' time), and between two store groups (64 symbols) it
+        // is not behind any store: vmcnt counts loads and stores together, in order, so a load issued after a store waits for it.
+        s32 ptr = (s32)srcSize - 8;
+        u64 cont = readLE64(src + ptr);
+        u64 lowHi = 0, lowLo = 0;
+        auto load_low = [&]() {
+            const s32 lp = ptr - 16;
+#if ZMI_LIT_EXPERIMENT == 2
+            lowHi = lowHi * 0x9E3779B97F4A7C15ull + (u64)lp; lowLo = lowHi ^ cont;
+#else
+            const u8* a = src + (lp > 0 ? lp : 0);
+            lowLo = readLE64(a); lowHi = readLE64(a + 8);
+#endif
+        };
+        auto fix_low = [&]() {           // bytes below the stream's start are zero (only the last steps of a stream get here)
+            const s32 lp = ptr - 16;
+            if (lp < 0) {
+                if (lp <= -16) { lowHi = 0; lowLo = 0; }
+                else {
+                    const u32 sh = 8u * (u32)(-lp);                 // 8 .. 120: the 16 loaded bytes are [0, 16), the wanted ones [lp, lp + 16)
+                    if (sh >= 64) { lowHi = lowLo << (sh - 64); lowLo = 0; }
+                    else { lowHi = (lowHi << sh) | (lowLo >> (64 - sh)); lowLo <<= sh; }
+                }
+            }
+        };
+        load_low();
+        const u32 last = (u32)(cont >> 56);
+        if (!last) return false;
+        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+        u32 consumed = 64u - (u32)(remaining - 8 * ptr);               // 1 .. 8
+        u32 hiTop;                                                     // the 4 bytes right below cont: all a window needs beyond cont
+        {   // (computed on a copy: the registers themselves are fixed where they are used, in the first step's re-base)
+            const u64 h0 = lowHi, l0 = lowLo;
+            fix_low(); hiTop = (u32)(lowHi >> 32);
+            lowHi = h0; lowLo = l0;
+        }
+        // one step = 8 symbols -> two dwords
+        auto step = [&](u32& word0, u32& word1) {
+            const u64 top = cont << consumed;                                          // the 96-bit window = (cont : hiTop) << consumed
+            const u64 mid = ((((u64)(u32)cont) << 32) | hiTop) << consumed;
+            u32 w = (u32)(top >> 32), r = (u32)(mid >> 32), q = (u32)mid, used = 0;
+            word0 = sym1(w, r, q, used); word0 |= sym1(w, r, q, used) << 8; word0 |= sym1(w, r, q, used) << 16; word0 |= sym1(w, r, q, used) << 24;
+            word1 = sym1(w, r, q, used); word1 |= sym1(w, r, q, used) << 8; word1 |= sym1(w, r, q, used) << 16; word1 |= sym1(w, r, q, used) << 24;
+            consumed += used;
+            // re-base by k whole bytes out of the 24 bytes in registers (now exact: the load issued a step ago has arrived)
+            fix_low();
+            const u32 k = consumed >> 3, j8 = 8u * (k & 7u);
+            const bool far = k >= 8;
+            const u64 X = far ? lowHi : cont, Y = far ? lowLo : lowHi, Z = far ? 0ull : lowLo;
+            cont = (X << j8) | (j8 ? Y >> (64 - j8) : 0ull);
+            const u64 hn = (Y << j8) | (j8 ? Z >> (64 - j8) : 0ull);     // (its top 4 bytes are exact for every k <= 12)
+            hiTop = (u32)(hn >> 32);
+            ptr -= (s32)k; consumed &= 7u;
+            load_low();
+        };
+        while (i + 64 <= n) {
+            u32 d[16];
+#pragma unroll
+            for (u32 g = 0; g < 8; ++g) step(d[2 * g], d[2 * g + 1]);
+#if ZMI_LIT_EXPERIMENT == 3
+            if ((i & 1023u) == 0) { u32 x = 0; for (u32 g = 0; g < 16; ++g) x ^= d[g]; *(u32u*)(out + i) = x; }
+#else
+            u32u* o = (u32u*)(out + i);
+#pragma unroll
+            for (u32 g = 0; g < 16; ++g) o[g] = d[g];
+#endif
+            i += 64;
+        }
+        while (i + 8 <= n) {
+            u32 d0, d1;
+            step(d0, d1);
+            u32u* o = (u32u*)(out + i); o[0] = d0; o[1] = d1;
+            i += 8;
+        }
+        remaining = 8 * ptr + 64 - (s32)consumed;
+    } else {
+        const u32 last = src[srcSize - 1];
+        if (!last) return false;
+        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
+    }
+    if (i < n && remaining > 0) {        // short stream, or the last symbols of a long one: plain bit reader
+        BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
+        while (i < n) {
+            u32 w = bd.peek(IDX + 1) << (31 - IDX), r = 0, q = 0, used = 0;
+            out[i++] = (u8)sym1(w, r, q, used);
+            bd.pos -= (s32)used;
+        }
+        remaining = bd.pos;
+    }
+    return i == n && remaining == 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // literals, fast path: kQuads frames per wave, 4 lanes (one per Huffman stream) per frame
 // ------------------------------------------------------------------------------------------------
 // The four streams of a block are four serial table-lookup chains, so a frame can keep only four lanes busy, and a
@@ -219,70 +363,6 @@ struct QuadLds {
 struct QuadScratch {            // view used by huf_read_stats: FSE scratch aliased onto the (not yet built) table
     u8* weights; s16* norm; u16* symbolNext; u16* wNewState; u8* wSymbol; u8* wNbBits;
 };
-
-// 4 symbols per step into one dword.  The loop body is branch-free: the container is re-based on EVERY step (by
-// consumed/8 bytes, possibly 0) from `lower`, the 8 stream bytes below it, whose load was issued one step earlier;
-// bytes below the stream start read as zero.  Keeping the refill unconditional is what lets the compiler place a
-// counted s_waitcnt in front of the use instead of draining every store (vmcnt counts loads and stores together).
-__device__ __forceinline__ bool huf_decode_stream4(const u16* __restrict__ table, u32 tableLog, const u8* __restrict__ src, u32 srcSize,
-                                                   u8* __restrict__ out, u32 n)
-{
-    if (srcSize < 1) return false;
-    s32 remaining; u32 i = 0;
-    if (srcSize >= 16) {
-        s32 ptr = (s32)srcSize - 8;                                    // byte index of the container; may go negative at the very end
-        u64 cont = readLE64(src + ptr);
-        u64 raw = readLE64(src + ptr - 8); s32 lp = ptr - 8;           // the 8 bytes below the container, fetched one step ahead
-        const u32 last = (u32)(cont >> 56);                            // (also makes the loop start with both loads retired)
-        if (!last) return false;
-        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-        u32 consumed = 64u - (u32)(remaining - 8 * ptr);
-        const u32 sh = 32 - tableLog;
-        // one step = 4 symbols -> one dword, then re-base the container and prefetch the next 8 bytes below it
-#define ZMI_HUF_STEP(word)                                                                                         \
-        {                                                                                                           \
-            u32 e;                                                                                                  \
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word = e & 0xFFu;                 \
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 8;         \
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 16;        \
-            e = table[(u32)((cont << consumed) >> 32) >> sh]; consumed += e >> 8; word |= (e & 0xFFu) << 24;        \
-            const u64 lower = lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0);                            \
-            const u32 k = consumed >> 3;                                                                            \
-            cont = (cont << (8 * k)) | (k ? (lower >> (64 - 8 * k)) : 0);                                           \
-            ptr -= (s32)k; consumed -= 8 * k;                                                                       \
-            lp = ptr - 8;                                                                                           \
-            raw = readLE64(src + (lp > 0 ? lp : 0));                                                                \
-        }
-        // 8 steps per store: vmcnt orders loads and stores together, so every store sits in front of the next
-        // prefetch wait; 32 symbols per (2 x 16 B) store keeps that exposure to once per 32 symbols
-        while (i + 32 <= n) {
-            u32 w0, w1, w2, w3, w4, w5, w6, w7;
-            ZMI_HUF_STEP(w0) ZMI_HUF_STEP(w1) ZMI_HUF_STEP(w2) ZMI_HUF_STEP(w3)
-            ZMI_HUF_STEP(w4) ZMI_HUF_STEP(w5) ZMI_HUF_STEP(w6) ZMI_HUF_STEP(w7)
-            u32u* o = (u32u*)(out + i);
-            o[0] = w0; o[1] = w1; o[2] = w2; o[3] = w3; o[4] = w4; o[5] = w5; o[6] = w6; o[7] = w7;
-            i += 32;
-        }
-        while (i + 4 <= n) {
-            u32 w;
-            ZMI_HUF_STEP(w)
-            *(u32u*)(out + i) = w;
-            i += 4;
-        }
-#undef ZMI_HUF_STEP
-        remaining = 8 * ptr + 64 - (s32)consumed;
-    } else {
-        const u32 last = src[srcSize - 1];
-        if (!last) return false;
-        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-    }
-    if (i < n && remaining > 0) {
-        BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
-        while (i < n) { const u32 e = table[bd.peek(tableLog)]; bd.pos -= (s32)(e >> 8); out[i++] = (u8)e; }
-        remaining = bd.pos;
-    }
-    return i == n && remaining == 0;
-}
 
 // rank starts -> per-symbol first index (HUF_readDTableX1), on the quad leader, after huf_read_stats
 __device__ __forceinline__ void quad_symbol_starts(QuadLds& Q, u32 nbSymbols, u32 tl)
@@ -312,11 +392,12 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const LitJob& J, const u32 ql)
     const u32 hs = Q.meta[0], nbSymbols = Q.meta[1], tableLog = Q.meta[2];
     if (!hs || (J.own ? hs >= J.hlen : hs > J.tlen)) return J.tErr;
     if (tableLog > 11) return 0xFFFFu;
+    const u32 up = 11 - tableLog;                      // the table is indexed by 11 bits: a smaller one is replicated 2^up times
     for (u32 n = ql; n < nbSymbols; n += 4) {          // table fill, 4 lanes
         const u32 w = Q.weights[n];
         if (!w) continue;
-        const u32 len = (1u << w) >> 1, st = Q.start[n];
-        const u32 e = n | ((tableLog + 1 - w) << 8);
+        const u32 len = ((1u << w) >> 1) << up, st = (u32)Q.start[n] << up;
+        const u32 e = huf_entry(n, tableLog + 1 - w);
         if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
         else for (u32 u = 0; u < len; u++) Q.huf[st + u] = (u16)e;
     }
@@ -324,12 +405,10 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const LitJob& J, const u32 ql)
     const u8* hsrc = J.hsrc; u32 hlen = J.hlen;
     if (J.own) { hsrc += hs; hlen -= hs; }
     bool ok = true;
-    if (J.single) {
-        if (ql == 0) ok = huf_decode_stream4(Q.huf, tableLog, hsrc, hlen, J.dst, J.litSize);
-    } else {
-        Streams4 S;
-        if (!streams4(S, hsrc, hlen, J.litSize, ql)) return kErrCorruption;
-        ok = huf_decode_stream4(Q.huf, tableLog, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
+    {   // one call site: a single-stream block is "stream 0 of 1" on the quad leader
+        Streams4 S; S.so = 0; S.sl = hlen; S.on = J.litSize; S.seg = 0;
+        if (!J.single && !streams4(S, hsrc, hlen, J.litSize, ql)) return kErrCorruption;
+        if (!J.single || ql == 0) ok = huf_decode_stream_fs<11, false>(Q.huf, nullptr, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
     }
     // any stream of the quad failing fails the block: combine through LDS (the 4 lanes are converged here)
     if (ql == 0) Q.meta[3] = 0;
@@ -353,76 +432,6 @@ struct CompactLds {
     u16 classFirst[14];         // index into sorted[] of the first symbol of class w
     u32 meta[4];
 };
-
-// n1 = number of 11-bit codes when tableLog = 11 (else 0).  In the canonical order (HUF_readDTableX1: weight classes ascending)
-// they own the first n1 entries of the 11-bit table, one each, i.e. the first n1/2 entries of the 10-bit table, two each: such
-// an entry holds BOTH symbols (low byte: next bit 0, high byte: next bit 1) and "index < n1/2" says so.  One LDS read per
-// symbol whatever the code length, no branch.
-__device__ __forceinline__ bool huf_decode_stream4c(const u16* __restrict__ table, const u8* __restrict__ sorted, u32 tableLog, u32 n1,
-                                                    const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
-{
-    if (srcSize < 1) return false;
-    const u32 idxBits = tableLog > 10 ? 10u : tableLog;
-    s32 remaining; u32 i = 0;
-    const u32 nPair = n1 >> 1;
-    (void)sorted;
-    auto lookup = [&](u32 top32) -> u32 {                 // top32 = the next 32 stream bits
-        const u32 idx = top32 >> (32 - idxBits);
-        const u32 sh = (top32 >> 18) & 8u;                // 8 x the bit after the 10 index bits (only used when tableLog = 11)
-        const u32 e = table[idx];
-        const u32 pairSym = ((e >> sh) & 0xFFu) | (11u << 8);
-        return idx < nPair ? pairSym : e;
-    };
-    if (srcSize >= 16) {
-        s32 ptr = (s32)srcSize - 8;
-        u64 cont = readLE64(src + ptr);
-        u64 raw = readLE64(src + ptr - 8); s32 lp = ptr - 8;
-        const u32 last = (u32)(cont >> 56);
-        if (!last) return false;
-        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-        u32 consumed = 64u - (u32)(remaining - 8 * ptr);
-#define ZMI_HUF_STEPC(word)                                                                                        \
-        {                                                                                                           \
-            u32 e;                                                                                                  \
-            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word = e & 0xFFu;                      \
-            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word |= (e & 0xFFu) << 8;              \
-            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word |= (e & 0xFFu) << 16;             \
-            e = lookup((u32)((cont << consumed) >> 32)); consumed += e >> 8; word |= (e & 0xFFu) << 24;             \
-            const u64 lower = lp >= 0 ? raw : (lp > -8 ? (raw << (8 * (u32)(-lp))) : 0);                            \
-            const u32 k = consumed >> 3;                                                                            \
-            cont = (cont << (8 * k)) | (k ? (lower >> (64 - 8 * k)) : 0);                                           \
-            ptr -= (s32)k; consumed -= 8 * k;                                                                       \
-            lp = ptr - 8;                                                                                           \
-            raw = readLE64(src + (lp > 0 ? lp : 0));                                                                \
-        }
-        while (i + 32 <= n) {
-            u32 w0, w1, w2, w3, w4, w5, w6, w7;
-            ZMI_HUF_STEPC(w0) ZMI_HUF_STEPC(w1) ZMI_HUF_STEPC(w2) ZMI_HUF_STEPC(w3)
-            ZMI_HUF_STEPC(w4) ZMI_HUF_STEPC(w5) ZMI_HUF_STEPC(w6) ZMI_HUF_STEPC(w7)
-            u32u* o = (u32u*)(out + i);
-            o[0] = w0; o[1] = w1; o[2] = w2; o[3] = w3; o[4] = w4; o[5] = w5; o[6] = w6; o[7] = w7;
-            i += 32;
-        }
-        while (i + 4 <= n) {
-            u32 w;
-            ZMI_HUF_STEPC(w)
-            *(u32u*)(out + i) = w;
-            i += 4;
-        }
-#undef ZMI_HUF_STEPC
-        remaining = 8 * ptr + 64 - (s32)consumed;
-    } else {
-        const u32 last = src[srcSize - 1];
-        if (!last) return false;
-        remaining = (s32)(srcSize - 1) * 8 + (s32)highbit32(last);
-    }
-    if (i < n && remaining > 0) {
-        BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
-        while (i < n) { const u32 e = lookup(bd.peek(11) << 21); bd.pos -= (s32)(e >> 8); out[i++] = (u8)e; }
-        remaining = bd.pos;
-    }
-    return i == n && remaining == 0;
-}
 
 // One block on the 4 lanes of a quad (compact tables).  Returns an error code, or 0xFFFF to ask for the slow path.
 __device__ u32 quad_decode_literals_c(CompactLds& Q, const LitJob& J, const u32 ql)
@@ -457,32 +466,34 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const LitJob& J, const u32 
     {   // table fill by the quad's 4 lanes, one symbol of `sorted` at a time
         const u32 nSorted = Q.classFirst[tableLog + 1];
         const u32 drop = tableLog > 10 ? 1u : 0u;          // 11-bit codes: the table is indexed by the upper 10 bits
+        const u32 up = tableLog < 10 ? 10 - tableLog : 0u; // a smaller table is replicated up to 10 index bits
         for (u32 k = ql; k < nSorted; k += 4) {
             u32 w = 1;
             for (u32 cw = 2; cw <= tableLog; ++cw) if (Q.classFirst[cw] <= k) w = cw;
             const u32 start = Q.classStart[w] + ((k - Q.classFirst[w]) << (w - 1));     // index in the tableLog-bit table
             const u32 sym = Q.sorted[k];
-            if (drop && w == 1) {                   // 11-bit codes: both symbols of the pair in one entry (see huf_decode_stream4c)
-                if (!(start & 1)) Q.huf[start >> 1] = (u16)(sym | ((u32)Q.sorted[k + 1] << 8));
+            if (drop && w == 1) {                   // 11-bit codes: one entry per pair, naming it (see huf_decode_stream_fs)
+                if (!(start & 1)) Q.huf[start >> 1] = (u16)(huf_entry(start >> 1, 11) | kEntPair);
                 continue;
             }
-            const u32 len = ((1u << w) >> 1) >> drop, st = start >> drop;
-            const u32 e = sym | ((tableLog + 1 - w) << 8);
+            const u32 len = (((1u << w) >> 1) >> drop) << up, st = (start >> drop) << up;
+            const u32 e = huf_entry(sym, tableLog + 1 - w);
             if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
             else for (u32 u = 0; u < len; u++) Q.huf[st + u] = (u16)e;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    const u32 n1 = tableLog > 10 ? Q.classFirst[2] : 0u;
+    const bool pairs = tableLog > 10;                  // (the pair list is the head of `sorted`: the 11-bit codes in table order)
     const u8* hsrc = J.hsrc; u32 hlen = J.hlen;
     if (J.own) { hsrc += hs; hlen -= hs; }
     bool ok = true;
-    if (J.single) {
-        if (ql == 0) ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, n1, hsrc, hlen, J.dst, J.litSize);
-    } else {
-        Streams4 S;
-        if (!streams4(S, hsrc, hlen, J.litSize, ql)) return kErrCorruption;
-        ok = huf_decode_stream4c(Q.huf, Q.sorted, tableLog, n1, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
+    {   // one call site per table form: a single-stream block is "stream 0 of 1" on the quad leader
+        Streams4 S; S.so = 0; S.sl = hlen; S.on = J.litSize; S.seg = 0;
+        if (!J.single && !streams4(S, hsrc, hlen, J.litSize, ql)) return kErrCorruption;
+        if (!J.single || ql == 0) {
+            if (pairs) ok = huf_decode_stream_fs<10, true>(Q.huf, Q.sorted, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
+            else       ok = huf_decode_stream_fs<10, false>(Q.huf, Q.sorted, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
+        }
     }
     if (ql == 0) Q.meta[3] = 0;
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
