@@ -9,8 +9,10 @@ typedef u64 __attribute__((aligned(1))) u64u; typedef u32 __attribute__((aligned
 static inline u32 highbit32(u32 v) { return 31u - (u32)__builtin_clz(v); }
 static inline u64 readLE64(const u8* p) { u64 v; memcpy(&v, p, 8); return v; }
 static inline u32 __builtin_amdgcn_alignbit(u32 hi, u32 lo, u32 s) { s &= 31; return (u32)((((u64)hi << 32) | lo) >> s); }
+static inline int __builtin_amdgcn_mov_dpp(int v, int, int, int, bool) { return v; }     // quad-transposed stores: GPU only, never taken here
 #define ZMI_LIT_EXPERIMENT 0
-constexpr u32 kEntPair = 0x20u;
+static u8 g_lds[1 << 16];                      // stands in for the LDS: tables are addressed by offset
+#define ZMI_LDS_U16(off) (*(const u16*)(g_lds + (off)))
 static inline u32 huf_entry(u32 sym, u32 nbBits) { return (32u - nbBits) | (sym << 8); }
 #include "bb.inc"
 #include "fs.inc"
@@ -56,14 +58,17 @@ int main(int argc, char** argv) {
             std::vector<u16> tab; bool pairs = false; u32 IDX = form == 0 ? 11 : 10;
             if (tableLog > IDX + (form == 1 ? 1 : 0)) continue;
             tab.assign(1u << IDX, 0);
+            const u32 tOff = 8192;                                   // aligned to the table size, like the kernels' LDS arrays
             if (tableLog <= IDX) { u32 up = IDX - tableLog; for (u32 i = 0; i < (1u << tableLog); i++) for (u32 u = 0; u < (1u << up); u++) tab[(i << up) + u] = (u16)huf_entry(full[i], c.nb[full[i]]); }
-            else { pairs = true; u32 n1 = 0; for (u32 sI = 0; sI < 256; sI++) n1 += w[sI] == 1; for (u32 i = 0; i < (1u << tableLog); i += 2) { if (i < n1) tab[i >> 1] = (u16)(huf_entry(i >> 1, 11) | kEntPair); else tab[i >> 1] = (u16)huf_entry(full[i], c.nb[full[i]]); } }
+            u32 n1 = 0;
+            if (tableLog > IDX) { pairs = true; for (u32 sI = 0; sI < 256; sI++) n1 += w[sI] == 1; for (u32 i = 0; i < (1u << tableLog); i += 2) { if (i < n1) tab[i >> 1] = (u16)(full[i] | (full[i + 1] << 8)); else tab[i >> 1] = (u16)huf_entry(full[i], c.nb[full[i]]); } }
             std::vector<u8> buf(32 + sz + 32, 0xAA); memcpy(buf.data() + 32, stream.data(), sz);      // guard bytes around the stream
             std::vector<u8> dec(n + 64, 0);
             bool ok;
-            if (form == 0) ok = huf_decode_stream_fs<11, false>(tab.data(), sorted.data(), buf.data() + 32, sz, dec.data(), n);
-            else ok = pairs ? huf_decode_stream_fs<10, true>(tab.data(), sorted.data(), buf.data() + 32, sz, dec.data(), n)
-                            : huf_decode_stream_fs<10, false>(tab.data(), sorted.data(), buf.data() + 32, sz, dec.data(), n);
+            memcpy(g_lds + tOff, tab.data(), tab.size() * 2);
+            if (form == 0) ok = huf_decode_stream_fs<11, false>(tOff, 0u, buf.data() + 32, sz, dec.data(), n);
+            else ok = pairs ? huf_decode_stream_fs<10, true>(tOff, n1, buf.data() + 32, sz, dec.data(), n)
+                            : huf_decode_stream_fs<10, false>(tOff, 0u, buf.data() + 32, sz, dec.data(), n);
             if (!ok || memcmp(dec.data(), syms.data(), n)) { u32 k = 0; while (k < n && dec[k] == syms[k]) k++; printf("iter %d form %d tableLog %u n %u sz %u ok %d firstbad %u\n", iter, form, tableLog, n, sz, ok, k); if (++bad > 10) return 1; }
         }
     }

@@ -150,6 +150,18 @@ __device__ inline void huf_build_table(LitLds& L, u32 nbSymbols, u32 tableLog, u
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
 }
 
+#ifndef ZMI_LIT_QUADSTORE
+#define ZMI_LIT_QUADSTORE 1
+#endif
+// true iff the predicate holds on all 4 lanes of this lane's quad (the quad's lanes are converged here)
+__device__ __forceinline__ bool quad_all(bool p, u32 ql)
+{
+    const u64 b = ballot(p);
+    const u32 base = lane_id() & ~3u;
+    (void)ql;
+    return ((b >> base) & 0xFull) == 0xFull;
+}
+
 // the four streams of a block: offsets and lengths from the 6-byte jump table (U/HufDecompress.cs:344-389); false = malformed
 struct Streams4 { u32 so, sl, on, seg; };
 __device__ __forceinline__ bool streams4(Streams4& S, const u8* hsrc, u32 hlen, u32 litSize, u32 which)
@@ -209,44 +221,54 @@ __global__ __launch_bounds__(64) void decode_literals_slow_kernel(const u8* __re
 // kept to three vector instructions around the LDS read:
 //     t = w >> (31 - IDX)          the index bits (and the bit behind them) of the 32-bit window w
 //     a = (t & mask) | tableBase   LDS address
-//     e = lds[a]                   entry: low 5 bits = 32 - nbBits, bit 5 = "pair", high byte = symbol (or pair number)
+//     e = lds[a]                   entry: low byte = 32 - nbBits, high byte = symbol
 //     w = alignbit(w, r, e)        v_alignbit_b32 takes its shift from the entry's low 5 bits as they are: {w, r} >> (32 - nbBits)
 // (r, q), the 64 bits behind the window, the output packing and the bit count follow off the chain.  After 8 symbols (at most
 // 88 of the 96 bits) the window is rebuilt from the byte stream, see the function body.
 // IDX = index bits of the table (tables of a smaller tableLog are replicated up to it).  PAIRS: tableLog = IDX + 1 is held in the
-// same table: the longest codes come in pairs sharing an IDX-bit prefix; their entry carries the pair's number and the symbol is
-// sorted[2 * pair + next bit] (sorted = symbols in (weight, symbol) order: its head is the pair list) — off the chain.
+// same table: the longest codes come in pairs sharing an IDX-bit prefix and own the first entries of the table (canonical order:
+// weight classes ascending); such an entry holds BOTH symbols (low byte: next bit 0, high byte: next bit 1), "index below the
+// pair count" says so before the entry has arrived, and its length is the constant IDX + 1: one select on the chain, no second read.
+// The table is addressed by its LDS offset (aligned to its size), so that index and base combine in one v_and_or_b32.
 // ------------------------------------------------------------------------------------------------
-constexpr u32 kEntPair = 0x20u;
 __device__ __forceinline__ u32 huf_entry(u32 sym, u32 nbBits) { return (32u - nbBits) | (sym << 8); }
+typedef __attribute__((address_space(3))) const u16 lds_u16_t;
+#define ZMI_LDS_U16(off) (*(lds_u16_t*)(size_t)(off))
+__device__ __forceinline__ u32 lds_offset(const void* p) { return (u32)(size_t)(__attribute__((address_space(3))) const u8*)p; }
 
 #ifndef ZMI_LIT_EXPERIMENT
 #define ZMI_LIT_EXPERIMENT 0            /* timing-only diagnostic builds (tools/lit_experiments.py): 1 no table lookup, 2 no stream loads, 3 no stores */
 #endif
 
+// quadStore (uniform over the 4 lanes of a quad that decode the 4 streams of one block): the first nQuad symbols (a multiple of
+// 64, the same for the 4 lanes) are written through a 4 x 4 transpose inside the quad (v_mov_dpp quad_perm, no LDS): lane j
+// then stores bytes [16 j, 16 j + 16) of stream p's 64-byte piece, p = 0 .. 3, so that every store instruction writes 64
+// contiguous bytes per stream instead of 16 — whole 64-byte sectors reach L2 / HBM (16-byte pieces were written back 2.4 times
+// over).  seg = distance between the output bases of consecutive streams, ql = this lane's stream.
 template <u32 IDX, bool PAIRS>
-__device__ __forceinline__ bool huf_decode_stream_fs(const u16* __restrict__ table, const u8* __restrict__ sorted,
-                                                     const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n)
+__device__ __forceinline__ bool huf_decode_stream_fs(const u32 tOff, const u32 nPair2,
+                                                     const u8* __restrict__ src, u32 srcSize, u8* __restrict__ out, u32 n,
+                                                     const bool quadStore = false, const u32 nQuad = 0, const u32 ql = 0, const u32 seg = 0)
 {
     if (srcSize < 1) return false;
     s32 remaining; u32 i = 0;
-    const u8* const tb = reinterpret_cast<const u8*>(table);
     constexpr u32 kMask = ((1u << IDX) - 1u) << 1;
-    // one symbol out of the 96-bit window (w, r, q): returns it, advances the window, adds its bits to `used`
-    auto sym1 = [&](u32& w, u32& r, u32& q, u32& used) -> u32 {
+    // one symbol out of the 96-bit window (w, r, q): returns it, advances the window, adds 32 - its bits to `spare`
+    // (nPair2 = twice the number of pair entries: t, which carries the bit behind the index, is below it exactly for them)
+    auto sym1 = [&](u32& w, u32& r, u32& q, u32& spare) -> u32 {
         const u32 t = w >> (31 - IDX);
 #if ZMI_LIT_EXPERIMENT == 1
         const u32 e = 26u | ((t & 0xFFu) << 8);
 #else
-        const u32 e = *reinterpret_cast<const u16*>(tb + (t & kMask));
+        const u32 e = ZMI_LDS_U16(tOff | (t & kMask));
 #endif
-        w = __builtin_amdgcn_alignbit(w, r, e);
-        r = __builtin_amdgcn_alignbit(r, q, e);
-        const u32 nb = (0u - e) & 31u;
-        q <<= nb; used += nb;
-        u32 sym = e >> 8;
-        if (PAIRS) { const u32 ps = sorted[(((e >> 8) << 1) | (t & 1u)) & 0xFFu]; sym = (e & kEntPair) ? ps : sym; }    // (pair numbers are < 128; the mask keeps other entries' reads inside `sorted`)
-        return sym;
+        u32 e2 = e, sh = 8;
+        if (PAIRS) { const bool isPair = t < nPair2; e2 = isPair ? 31u - IDX : e; sh = isPair ? (t & 1u) << 3 : 8u; }
+        w = __builtin_amdgcn_alignbit(w, r, e2);
+        r = __builtin_amdgcn_alignbit(r, q, e2);
+        q = __builtin_amdgcn_alignbit(q, 0u, e2);
+        spare += e2 & 0xFFu;
+        return (e >> sh) & 0xFFu;
     };
     if (srcSize >= 16) {
         // The stream is read from its last byte down.  cont = stream bytes [ptr, ptr + 8); (lowHi, lowLo) = the 16 bytes below it,
@@ -294,10 +316,10 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u16* __restrict__ tab
         auto step = [&](u32& word0, u32& word1) {
             const u64 top = cont << consumed;                                          // the 96-bit window = (cont : hiTop) << consumed
             const u64 mid = ((((u64)(u32)cont) << 32) | hiTop) << consumed;
-            u32 w = (u32)(top >> 32), r = (u32)(mid >> 32), q = (u32)mid, used = 0;
-            word0 = sym1(w, r, q, used); word0 |= sym1(w, r, q, used) << 8; word0 |= sym1(w, r, q, used) << 16; word0 |= sym1(w, r, q, used) << 24;
-            word1 = sym1(w, r, q, used); word1 |= sym1(w, r, q, used) << 8; word1 |= sym1(w, r, q, used) << 16; word1 |= sym1(w, r, q, used) << 24;
-            consumed += used;
+            u32 w = (u32)(top >> 32), r = (u32)(mid >> 32), q = (u32)mid, spare = 0;
+            word0 = sym1(w, r, q, spare); word0 |= sym1(w, r, q, spare) << 8; word0 |= sym1(w, r, q, spare) << 16; word0 |= sym1(w, r, q, spare) << 24;
+            word1 = sym1(w, r, q, spare); word1 |= sym1(w, r, q, spare) << 8; word1 |= sym1(w, r, q, spare) << 16; word1 |= sym1(w, r, q, spare) << 24;
+            consumed += 8u * 32u - spare;
             // re-base by k whole bytes out of the 24 bytes in registers (now exact: the load issued a step ago has arrived)
             fix_low();
             const u32 k = consumed >> 3, j8 = 8u * (k & 7u);
@@ -309,6 +331,41 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u16* __restrict__ tab
             ptr -= (s32)k; consumed &= 7u;
             load_low();
         };
+        if (quadStore) {
+            const bool odd1 = ql & 1u, odd2 = ql & 2u;
+            u8* const tbase = out - (size_t)ql * seg + 16u * ql;       // stream 0's base + this lane's 16-byte column
+            while (i + 64 <= nQuad) {
+                u32 d[16];
+#pragma unroll
+                for (u32 g = 0; g < 8; ++g) step(d[2 * g], d[2 * g + 1]);
+                // 4 x 4 transpose of 16-byte pieces over the quad's lanes: piece p of lane l <-> piece l of lane p
+                u32 b[16], c[16];
+#pragma unroll
+                for (u32 p = 0; p < 4; ++p)
+#pragma unroll
+                    for (u32 k = 0; k < 4; ++k) {
+                        const u32 nb1 = (u32)__builtin_amdgcn_mov_dpp((int)d[4 * (p ^ 1u) + k], 0xB1, 0xF, 0xF, true);    // lane ^ 1's piece p ^ 1
+                        b[4 * p + k] = (odd1 == (bool)(p & 1u)) ? d[4 * p + k] : nb1;
+                    }
+#pragma unroll
+                for (u32 p = 0; p < 4; ++p)
+#pragma unroll
+                    for (u32 k = 0; k < 4; ++k) {
+                        const u32 nb2 = (u32)__builtin_amdgcn_mov_dpp((int)b[4 * (p ^ 2u) + k], 0x4E, 0xF, 0xF, true);    // lane ^ 2's piece p ^ 2
+                        c[4 * p + k] = (odd2 == (bool)(p & 2u)) ? b[4 * p + k] : nb2;
+                    }
+#if ZMI_LIT_EXPERIMENT == 3
+                if ((i & 1023u) == 0) { u32 x = 0; for (u32 g = 0; g < 16; ++g) x ^= c[g]; *(u32u*)(out + i) = x; }
+#else
+#pragma unroll
+                for (u32 p = 0; p < 4; ++p) {
+                    u32u* o = (u32u*)(tbase + (size_t)p * seg + i);
+                    o[0] = c[4 * p]; o[1] = c[4 * p + 1]; o[2] = c[4 * p + 2]; o[3] = c[4 * p + 3];
+                }
+#endif
+                i += 64;
+            }
+        }
         while (i + 64 <= n) {
             u32 d[16];
 #pragma unroll
@@ -337,9 +394,9 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u16* __restrict__ tab
     if (i < n && remaining > 0) {        // short stream, or the last symbols of a long one: plain bit reader
         BackBits bd; bd.base = src; bd.size = (s32)srcSize; bd.pos = remaining; bd.load_window(remaining);
         while (i < n) {
-            u32 w = bd.peek(IDX + 1) << (31 - IDX), r = 0, q = 0, used = 0;
-            out[i++] = (u8)sym1(w, r, q, used);
-            bd.pos -= (s32)used;
+            u32 w = bd.peek(IDX + 1) << (31 - IDX), r = 0, q = 0, spare = 0;
+            out[i++] = (u8)sym1(w, r, q, spare);
+            bd.pos -= (s32)(32u - spare);
         }
         remaining = bd.pos;
     }
@@ -354,8 +411,9 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u16* __restrict__ tab
 // lanes per CU) and the length of one lookup step; packing 8 frames into a wave lets one wave instruction advance
 // 32 streams instead of 4, which is what the one-frame-per-wave form wasted its issue slots on.
 constexpr u32 kQuads = 8;
+// (the X1 tables live in their own LDS array, aligned to their size: huf_decode_stream_fs; before a table is filled its storage
+//  holds the FSE scratch of huf_read_stats)
 struct QuadLds {
-    u16 huf[2048];              // X1 table (tableLog <= 11).  Before it is filled, its storage holds the FSE scratch below.
     u8  weights[256];
     u16 start[256];             // first table index of each symbol
     u32 meta[4];                // hs, nbSymbols, tableLog, valid
@@ -377,12 +435,12 @@ __device__ __forceinline__ void quad_symbol_starts(QuadLds& Q, u32 nbSymbols, u3
 // One block on the 4 lanes of a quad.  The job is computed redundantly by the 4 lanes (same loads, same values, so the quad's
 // control flow is uniform without any cross-lane traffic); only the weight decoding runs on the quad leader.
 // Returns an error code, or 0xFFFF to ask for the slow path (12-bit table).
-__device__ u32 quad_decode_literals(QuadLds& Q, const LitJob& J, const u32 ql)
+__device__ u32 quad_decode_literals(u16* __restrict__ huf, QuadLds& Q, const LitJob& J, const u32 ql)
 {
     if (ql == 0) {
         QuadScratch sc;
-        sc.weights = Q.weights; sc.norm = reinterpret_cast<s16*>(Q.huf); sc.symbolNext = Q.huf + 256;
-        sc.wNewState = Q.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(Q.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(Q.huf + 608);
+        sc.weights = Q.weights; sc.norm = reinterpret_cast<s16*>(huf); sc.symbolNext = huf + 256;
+        sc.wNewState = huf + 512; sc.wSymbol = reinterpret_cast<u8*>(huf + 576); sc.wNbBits = reinterpret_cast<u8*>(huf + 608);
         u32 nbSymbols = 0, tl = 0;
         const u32 hs = huf_read_stats(sc, J.tsrc, J.tlen, &nbSymbols, &tl);
         if (hs && tl <= 11) quad_symbol_starts(Q, nbSymbols, tl);
@@ -398,8 +456,8 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const LitJob& J, const u32 ql)
         if (!w) continue;
         const u32 len = ((1u << w) >> 1) << up, st = (u32)Q.start[n] << up;
         const u32 e = huf_entry(n, tableLog + 1 - w);
-        if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
-        else for (u32 u = 0; u < len; u++) Q.huf[st + u] = (u16)e;
+        if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&huf[st + u]) = e4; }
+        else for (u32 u = 0; u < len; u++) huf[st + u] = (u16)e;
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
     const u8* hsrc = J.hsrc; u32 hlen = J.hlen;
@@ -408,7 +466,11 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const LitJob& J, const u32 ql)
     {   // one call site: a single-stream block is "stream 0 of 1" on the quad leader
         Streams4 S; S.so = 0; S.sl = hlen; S.on = J.litSize; S.seg = 0;
         if (!J.single && !streams4(S, hsrc, hlen, J.litSize, ql)) return kErrCorruption;
-        if (!J.single || ql == 0) ok = huf_decode_stream_fs<11, false>(Q.huf, nullptr, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
+        // (the four streams hold seg, seg, seg and <= seg symbols, and every one of them at least 16 bytes of input when the
+        //  transposed stores are used: the group loop then runs the same number of times on the 4 lanes)
+        const u32 lastOn = J.litSize - 3 * S.seg;
+        const bool quadStore = !J.single && ZMI_LIT_QUADSTORE && quad_all(S.sl >= 16, ql);
+        if (!J.single || ql == 0) ok = huf_decode_stream_fs<11, false>(lds_offset(huf), 0u, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on, quadStore, lastOn & ~63u, ql, S.seg);
     }
     // any stream of the quad failing fails the block: combine through LDS (the 4 lanes are converged here)
     if (ql == 0) Q.meta[3] = 0;
@@ -419,28 +481,30 @@ __device__ u32 quad_decode_literals(QuadLds& Q, const LitJob& J, const u32 ql)
 }
 
 // =====================================================================================================================
-// Literal decoder, serial form, COMPACT tables: what bounds the serial form is LDS (a 4 KiB table per frame admits 32
-// frames per CU, so 16 384 frames take two rounds).  Here the table is indexed by at most 10 bits (2 KiB); for tableLog 11
-// the longest codes (weight 1) come in pairs that share a 10-bit prefix: their entry is an escape (0xF000 | pair) and one
-// more bit picks the symbol out of `sorted`, the list of symbols in (weight, symbol) order whose head IS the pair table.
-// 2.4 KiB per frame -> 64 frames per CU -> one round.  Same acceptance as the other forms; tableLog 12 goes the slow way.
+// Literal decoder, serial form, COMPACT tables: what bounds the serial form is LDS (a 4 KiB table per block admits 32 blocks
+// per CU, so 16 384 blocks take two rounds).  Here the table is indexed by at most 10 bits (2 KiB); for tableLog 11 the longest
+// codes (weight 1) come in pairs that share a 10-bit prefix, and a pair's entry holds both symbols (huf_decode_stream_fs).
+// 2.4 KiB per block -> 64 blocks per CU -> one round, as FOUR workgroups of 16 blocks: a wave works with all its 64 lanes (16
+// quads), i.e. half the instructions of two half-filled waves, and has its SIMD's issue slots to itself.
+// Same acceptance as the other forms; tableLog 12 goes the slow way.
 // =====================================================================================================================
-struct CompactLds {
-    u16 huf[1024];              // byte | nbBits << 8; the first n1/2 entries (owned by pairs of 11-bit codes): symbol(bit 0) | symbol(bit 1) << 8.  Before it is filled: FSE scratch (low 1280 B) and the weights (top 256 B)
-    u8  sorted[256];            // symbols ordered by (weight, symbol), weight 0 excluded; its head = the 11-bit codes in table order
+constexpr u32 kQuadsC = 16;
+struct CompactLds {             // (the tables live in their own LDS array, aligned to their size; before a table is filled its
+    u8  sorted[256];            //  storage holds the FSE scratch, low 1280 B, and the weights, top 256 B)
+                                // sorted: symbols ordered by (weight, symbol), weight 0 excluded; its head = the 11-bit codes in table order
     u16 classStart[14];         // first index (in the tableLog-bit table) of weight class w; [tableLog + 1] = table size
     u16 classFirst[14];         // index into sorted[] of the first symbol of class w
     u32 meta[4];
 };
 
 // One block on the 4 lanes of a quad (compact tables).  Returns an error code, or 0xFFFF to ask for the slow path.
-__device__ u32 quad_decode_literals_c(CompactLds& Q, const LitJob& J, const u32 ql)
+__device__ u32 quad_decode_literals_c(u16* __restrict__ huf, CompactLds& Q, const LitJob& J, const u32 ql)
 {
-    u8* const weights = reinterpret_cast<u8*>(Q.huf + 896);     // top 256 B of the table area until the fill
+    u8* const weights = reinterpret_cast<u8*>(huf + 896);       // top 256 B of the table area until the fill
     if (ql == 0) {
         QuadScratch sc;
-        sc.weights = weights; sc.norm = reinterpret_cast<s16*>(Q.huf); sc.symbolNext = Q.huf + 256;
-        sc.wNewState = Q.huf + 512; sc.wSymbol = reinterpret_cast<u8*>(Q.huf + 576); sc.wNbBits = reinterpret_cast<u8*>(Q.huf + 608);
+        sc.weights = weights; sc.norm = reinterpret_cast<s16*>(huf); sc.symbolNext = huf + 256;
+        sc.wNewState = huf + 512; sc.wSymbol = reinterpret_cast<u8*>(huf + 576); sc.wNbBits = reinterpret_cast<u8*>(huf + 608);
         u32 nbSymbols = 0, tl = 0;
         const u32 hs = huf_read_stats(sc, J.tsrc, J.tlen, &nbSymbols, &tl);
         if (hs && tl <= 11) {          // class extents (HUF_readDTableX1) and the symbols in (weight, symbol) order
@@ -472,27 +536,30 @@ __device__ u32 quad_decode_literals_c(CompactLds& Q, const LitJob& J, const u32 
             for (u32 cw = 2; cw <= tableLog; ++cw) if (Q.classFirst[cw] <= k) w = cw;
             const u32 start = Q.classStart[w] + ((k - Q.classFirst[w]) << (w - 1));     // index in the tableLog-bit table
             const u32 sym = Q.sorted[k];
-            if (drop && w == 1) {                   // 11-bit codes: one entry per pair, naming it (see huf_decode_stream_fs)
-                if (!(start & 1)) Q.huf[start >> 1] = (u16)(huf_entry(start >> 1, 11) | kEntPair);
+            if (drop && w == 1) {                   // 11-bit codes: both symbols of the pair in one entry (see huf_decode_stream_fs)
+                if (!(start & 1)) huf[start >> 1] = (u16)(sym | ((u32)Q.sorted[k + 1] << 8));
                 continue;
             }
             const u32 len = (((1u << w) >> 1) >> drop) << up, st = (start >> drop) << up;
             const u32 e = huf_entry(sym, tableLog + 1 - w);
-            if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&Q.huf[st + u]) = e4; }
-            else for (u32 u = 0; u < len; u++) Q.huf[st + u] = (u16)e;
+            if (len >= 4) { const u64 e4 = (u64)(e | (e << 16)) * 0x100000001ull; for (u32 u = 0; u < len; u += 4) *reinterpret_cast<u64*>(&huf[st + u]) = e4; }
+            else for (u32 u = 0; u < len; u++) huf[st + u] = (u16)e;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-    const bool pairs = tableLog > 10;                  // (the pair list is the head of `sorted`: the 11-bit codes in table order)
+    const bool pairs = tableLog > 10;
+    const u32 nPair2 = pairs ? (u32)Q.classFirst[2] : 0u;      // the 11-bit codes = weight class 1: n1 of them, n1 / 2 pair entries, t < n1
     const u8* hsrc = J.hsrc; u32 hlen = J.hlen;
     if (J.own) { hsrc += hs; hlen -= hs; }
     bool ok = true;
     {   // one call site per table form: a single-stream block is "stream 0 of 1" on the quad leader
         Streams4 S; S.so = 0; S.sl = hlen; S.on = J.litSize; S.seg = 0;
         if (!J.single && !streams4(S, hsrc, hlen, J.litSize, ql)) return kErrCorruption;
+        const u32 lastOn = J.litSize - 3 * S.seg;
+        const bool quadStore = !J.single && ZMI_LIT_QUADSTORE && quad_all(S.sl >= 16, ql);
         if (!J.single || ql == 0) {
-            if (pairs) ok = huf_decode_stream_fs<10, true>(Q.huf, Q.sorted, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
-            else       ok = huf_decode_stream_fs<10, false>(Q.huf, Q.sorted, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on);
+            if (pairs) ok = huf_decode_stream_fs<10, true>(lds_offset(huf), nPair2, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on, quadStore, lastOn & ~63u, ql, S.seg);
+            else       ok = huf_decode_stream_fs<10, false>(lds_offset(huf), 0u, hsrc + S.so, S.sl, J.dst + ql * S.seg, S.on, quadStore, lastOn & ~63u, ql, S.seg);
         }
     }
     if (ql == 0) Q.meta[3] = 0;
@@ -507,15 +574,16 @@ __global__ __launch_bounds__(64) void decode_literals_compact_kernel(const u8* _
                                                                      u32* __restrict__ status, u8* __restrict__ slowFlags,
                                                                      const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
-    __shared__ CompactLds Qs[kQuads];
+    __shared__ __attribute__((aligned(2048))) u16 tables[kQuadsC][1024];
+    __shared__ CompactLds Qs[kQuadsC];
     const u32 lane = threadIdx.x, q = lane >> 2, ql = lane & 3;
-    const u32 bi = blockIdx.x * kQuads + q;
-    if (q >= kQuads || bi >= nBlocks) return;          // (a wave holds kQuads quads: its upper lanes have no table to work with)
+    const u32 bi = blockIdx.x * kQuadsC + q;
+    if (bi >= nBlocks) return;
     if (ql == 0) slowFlags[bi] = 0;
     if (status[kStErr]) return;
     LitJob J;
     if (!lit_job(J, bi, blocks, frames, src, out, scratch, dictFull, di)) return;
-    const u32 err = quad_decode_literals_c(Qs[q], J, ql);
+    const u32 err = quad_decode_literals_c(tables[q], Qs[q], J, ql);
     if (ql == 0) {
         if (err == 0xFFFFu) slowFlags[bi] = 1;
         else if (err) report_error(status, bi, kStageLiterals, err);
@@ -527,6 +595,7 @@ __global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restric
                                                              u32* __restrict__ status, u8* __restrict__ slowFlags,
                                                              const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
+    __shared__ __attribute__((aligned(4096))) u16 tables[kQuads][2048];
     __shared__ QuadLds Qs[kQuads];
     const u32 lane = threadIdx.x, q = lane >> 2, ql = lane & 3;
     const u32 bi = blockIdx.x * kQuads + q;
@@ -535,7 +604,7 @@ __global__ __launch_bounds__(64) void decode_literals_kernel(const u8* __restric
     if (status[kStErr]) return;
     LitJob J;
     if (!lit_job(J, bi, blocks, frames, src, out, scratch, dictFull, di)) return;
-    const u32 err = quad_decode_literals(Qs[q], J, ql);
+    const u32 err = quad_decode_literals(tables[q], Qs[q], J, ql);
     if (ql == 0) {
         if (err == 0xFFFFu) slowFlags[bi] = 1;
         else if (err) report_error(status, bi, kStageLiterals, err);
@@ -860,7 +929,7 @@ void launch_decode_literals(const u8* src, u8* out, u8* scratch, const FrameDesc
         hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nBlocks), dim3(256), sizeof(SyncLds), stream, src, out, scratch, frames, blocks, nBlocks, status, dictFull, di);
         return;
     }
-    if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nBlocks + kQuads - 1) / kQuads), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, slowFlags, dictFull, di);
+    if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nBlocks + kQuadsC - 1) / kQuadsC), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, slowFlags, dictFull, di);
     else           hipLaunchKernelGGL(decode_literals_kernel, dim3((nBlocks + kQuads - 1) / kQuads), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, slowFlags, dictFull, di);
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nBlocks), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, (const u8*)slowFlags, dictFull, di);
 }
