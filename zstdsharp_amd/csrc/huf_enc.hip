@@ -271,13 +271,14 @@ __device__ __forceinline__ u32 min_gain(u32 srcSize) { return (srcSize >> 6) + 2
 // Front half: everything that is parallel over the literals or over the 256 symbols.  Hands the sorted leaves, the four
 // per-stream histograms and the verdicts to huf_tree_kernel through the chunk's (still unused) output slot.
 __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ lits, const ChunkMeta* __restrict__ meta,
-                                                       u8* __restrict__ slots, const u32 rawLiterals)
+                                                       u8* __restrict__ slots, const u32 rawLiterals, const u8* __restrict__ src, const u32 chunkBytes)
 {
     __shared__ HufBuildLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const u32 litSize = meta[c].litSize, nbSeqIn = meta[c].nbSeq;
     HufWork* __restrict__ W = reinterpret_cast<HufWork*>(slots + (u64)c * kSlotStride);
-    const u8* __restrict__ lit = lits + (u64)c * kLitStride;
+    // (a chunk without sequences never copied its literals: they are its source bytes, lz_fast.hip)
+    const u8* __restrict__ lit = meta[c].litFromSrc ? src + (u64)c * chunkBytes : lits + (u64)c * kLitStride;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
@@ -294,9 +295,9 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
         const u32 s0 = wave * seg, s1 = (s0 + seg < litSize) ? s0 + seg : litSize;
         u32* H = L.hist[wave][lane & 1];      // two copies per wave, by lane parity: halves same-address atomic serialisation
         if (s0 < s1) {
-            // 16 bytes per lane per load (the literal buffer is 64 KiB-aligned): a byte-per-lane loop is bound by one
-            // global-load latency per 64 bytes
-            u32 a0 = (s0 + 15) & ~15u; if (a0 > s1) a0 = s1;
+            // 16 bytes per lane per load (aligned: the literal buffer is, a caller's source need not be): a byte-per-lane loop is
+            // bound by one global-load latency per 64 bytes
+            u32 a0 = s0 + ((0u - (u32)(uintptr_t)(lit + s0)) & 15u); if (a0 > s1) a0 = s1;
             if (s0 + lane < a0) atomicAdd(&H[lit[s0 + lane]], 1u);
             const u32 nVec = (s1 - a0) >> 4;
             const uint4* v4 = reinterpret_cast<const uint4*>(lit + a0);
@@ -553,7 +554,7 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
         m.streamSize[0] = streamSize[0]; m.streamSize[1] = streamSize[1]; m.streamSize[2] = streamSize[2]; m.streamSize[3] = streamSize[3];
         m.litSectionSize = lhSize + cLitSize;
     } else if (rle) {
-        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.pad[0] = shRleByte;
+        m.litMode = kLitRle; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + 1; m.rleByte = shRleByte;
     } else {
         m.litMode = kLitRaw; m.lhSize = lhSizeRaw; m.litSectionSize = lhSizeRaw + litSize;
     }
@@ -586,13 +587,14 @@ struct HufEncLds {
 // sequences section and the headers follow through gather_kernel); nullptr: into the chunk's slot (test hook).
 __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ lits, const ChunkMeta* __restrict__ meta,
                                                          const HufTable* __restrict__ tables, u8* __restrict__ slots,
-                                                         u8* __restrict__ dst, const u64* __restrict__ offsets, u64 dstCapacity)
+                                                         u8* __restrict__ dst, const u64* __restrict__ offsets, u64 dstCapacity,
+                                                         const u8* __restrict__ src, const u32 chunkBytes)
 {
     __shared__ HufEncLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
     const ChunkMeta m = meta[c];
     const u32 litSize = m.litSize;
-    const u8* __restrict__ lit = lits + (u64)c * kLitStride;
+    const u8* __restrict__ lit = m.litFromSrc ? src + (u64)c * chunkBytes : lits + (u64)c * kLitStride;
     u8* __restrict__ body = slots + (u64)c * kSlotStride + m.fhSize + 3;      // block body starts after frame + block header
     if (dst) {
         if (m.blockType != 2) return;                                        // stored raw: gather copies the source bytes
@@ -610,7 +612,7 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
             case 2: writeLE16(body, type + (1u << 2) + (litSize << 4)); break;
             default: writeLE24(body, type + (3u << 2) + (litSize << 4)); break;
             }
-            if (type == 1) body[m.lhSize] = (u8)m.pad[0];
+            if (type == 1) body[m.lhSize] = (u8)m.rleByte;
         }
         if (type == 0) for (u32 i = tid; i < litSize; i += 256) body[m.lhSize + i] = lit[i];
         return;
@@ -695,15 +697,16 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
     }
 }
 
-void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, hipStream_t stream)
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
+                      hipStream_t stream)
 {
-    hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots, rawLiterals);
+    hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots, rawLiterals, src, chunkBytes);
     hipLaunchKernelGGL(huf_tree_kernel, dim3(nChunks), dim3(64), 0, stream, meta, tables, slots, rawLiterals);
 }
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
-                       u32 nChunks, hipStream_t stream)
+                       u32 nChunks, const u8* src, u32 chunkBytes, hipStream_t stream)
 {
-    hipLaunchKernelGGL(huf_encode_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables, slots, dst, offsets, dstCapacity);
+    hipLaunchKernelGGL(huf_encode_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, tables, slots, dst, offsets, dstCapacity, src, chunkBytes);
 }
 
 } // namespace zmi

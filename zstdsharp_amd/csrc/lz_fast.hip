@@ -221,6 +221,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // parse state, kept identically in every thread's registers (all updates come from LDS values read after a barrier)
     u32 cursor = hist;   // absolute position where the parse of the previous tiles ended (= end of the last selected match)
     u32 nbSeq = 0, litBase = 0;
+    // As long as the chunk has no sequence its literals are its own bytes from the start: they are counted, not copied.  The first
+    // selected match makes up for it (one copy out of LDS); a chunk that ends without sequences never writes its literals at all
+    // and the entropy stage reads them from the source (ChunkMeta::litFromSrc) — incompressible-by-LZ data, e.g. BASELINE's Zipf bytes.
+    bool deferred = true;
 
     // one selected match -> its sequence + its coverage bits (used by the dense and the sparse path)
     u32 covPar = 0;                      // coverage-mask slot of the current tile
@@ -599,8 +603,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             // (a super-tile may hold more than 64 matches: they are walked 64 at a time, at most kSuperMax of them — the
             //  rest stays literals; it happens where sparse data turns dense, and the next tile is a dense one)
             if (wave == 0) {
-                constexpr u32 kSuperMax = 1024;
+                constexpr u32 kSuperMax = 1024, kFrugalLen = 12;
                 const u32 mcount = matchCount < kSuperMax ? matchCount : kSuperMax;
+                const bool frugal = matchCount <= 2;
                 const u64 mmw = L.matchMask[lane];                     // lane = group of 64 array slots
                 const u32 cntW = popc64(mmw);
                 const u32 rankW = wave_scan_incl(cntW) - cntW;          // matches before this lane's group
@@ -622,6 +627,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                         const u32 qi = read_lane(q, i);
                         if (qi < cur) continue;
                         const u32 li = read_lane(len, i);
+                        // one or two short matches in 4-16 KiB do not pay for a sequences section (a lone sequence costs about
+                        // four bytes, a 6-byte match saves about as much): they stay literals, and a chunk with nothing else
+                        // stays a pure literals block — no sequence stages on either side, literals decoded in place
+                        if (frugal && li < kFrugalLen) continue;
                         u32 e = tileStart + qi + li;
                         if (li == kLenCap) e = finish_capped(tileStart + qi, read_lane(off, i));
                         if (lane == i) myEnd = e;
@@ -646,15 +655,27 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
         const u32 nSub = span >> kTileLog;          // 1, or up to 16 in a super-tile: the compaction below runs per 4096 positions
         // sixteen positions per thread: a tile takes 256 threads, four sub-tiles of a super-tile all 1024 (one pass per four)
-        if (!any && c0 == 0 && tileStart + span <= n) {
-            // nothing selected, nothing carried in, full tile: every byte is a literal, copied straight through
-            for (u32 q16 = tid * 16; q16 < span; q16 += kTile * 16) {
-                const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
-                u32u* o = (u32u*)(litOut + litBase + q16);
-                o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        if (nSel == 0 && c0 == 0) {
+            // nothing selected, nothing carried in: every byte of the tile (what there is of it) is a literal
+            const u32 bytes = tileStart + span <= n ? span : n - tileStart;
+            if (!deferred) {                     // (uniform) copied straight through
+                for (u32 q16 = tid * 16; q16 < bytes; q16 += kTile * 16) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(L.in + tileStart + q16);
+                    u8* o1 = litOut + litBase + q16;
+                    if (q16 + 16 <= bytes) { u32u* o = (u32u*)o1; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; }
+                    else for (u32 k = 0; q16 + k < bytes; ++k) o1[k] = L.in[tileStart + q16 + k];
+                }
             }
-            litBase += span;
+            litBase += bytes;
         } else {
+            if (deferred && !histTile) {         // (uniform) the first tile that is not all literals: the bytes counted so far, out of LDS
+                for (u32 q16 = tid * 16; q16 < litBase; q16 += kTile * 16) {
+                    const uint4 v = *reinterpret_cast<const uint4*>(L.in + hist + q16);
+                    u32u* o = (u32u*)(litOut + q16);             // (litBase is a multiple of 4096 here: whole tiles only)
+                    o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+                }
+                deferred = false;
+            }
             const u32 lastEnd = nSel ? endOf[nSel] : cursor;
             // Every wave scans the group words itself (one LDS read per lane and sub-tile), so the compaction offsets need
             // neither a cross-wave table nor another barrier.  keepG(sub, g) = bytes of group g of sub-tile `sub` that are
@@ -710,6 +731,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     if (tid == 0) {
         ChunkMeta m = {};
         m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(nData) + fhExtra;      // fhExtra: bytes of the dictID field (formatted dictionary), else 0
+        m.litFromSrc = deferred ? 1u : 0u;       // (then nbSeq = 0 and litBase = nData: the literals are the chunk itself)
         meta[c] = m;
     }
 }

@@ -48,7 +48,8 @@ struct ChunkMeta {
     u32 blockType;      // 0 raw, 1 RLE, 2 compressed
     u32 outSize;        // frame bytes in the slot (header + block + optional checksum)
     u32 checksum;       // low 32 bits of XXH64 of the chunk when the checksum flag is set
-    u32 pad[2];
+    u32 rleByte;        // the byte of an RLE literals section
+    u32 litFromSrc;     // 1 = the chunk has no sequences and its literals were never copied: they ARE the chunk's source bytes
 };
 
 // Huffman code table for one chunk (HBM): canonical codes as the reference assigns them (U/HufCompress.cs:750-788)

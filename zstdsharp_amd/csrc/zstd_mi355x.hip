@@ -19,9 +19,10 @@ namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream);
-void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, hipStream_t stream);
+void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
+                      hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
-                       u32 nChunks, hipStream_t stream);
+                       u32 nChunks, const u8* src, u32 chunkBytes, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
                        u32 dictID, u32 dictIdBytes, const u32* initReps, hipStream_t stream);
 void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
@@ -120,6 +121,7 @@ struct ZSTD_CCtx_s {
     hipStream_t ownStream = nullptr, stream = nullptr;
     DevBuf seqs, lits, meta, tables, slots, offsets, total, stageSrc, stageDst;
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
+    const u8* lastSrc = nullptr; u32 lastChunkBytes = 0;     // its source (debug hook: chunks without sequences keep their literals there)
     u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
     // streaming adapter (ZSTD_compressStream2): host-side batching in front of the one-shot engine
     std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
@@ -302,13 +304,13 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
         launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, s);      c->timer.mark("lz_fast", s);
-        launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, s);        c->timer.mark("huf_build", s);
+        launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s);        c->timer.mark("huf_build", s);
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, s);   c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
-        launch_huf_encode(lits, meta, tables, slots, d_dst + produced, offsets, room, nChunks, s);   c->timer.mark("huf_encode", s);
+        launch_huf_encode(lits, meta, tables, slots, d_dst + produced, offsets, room, nChunks, src, chunkBytes, s);   c->timer.mark("huf_encode", s);
         launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, chunkBytes, s);      c->timer.mark("gather", s);
         u64 passTotal = 0;
         if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
@@ -319,7 +321,7 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         first = false;
         if (passTotal > room) return ZERR(kErrDstSizeTooSmall);
         produced += (size_t)passTotal;
-        c->lastChunks = nChunks;
+        c->lastChunks = nChunks; c->lastSrc = src; c->lastChunkBytes = chunkBytes;
     }
     return produced;
 }
@@ -971,7 +973,8 @@ size_t ZSTDMI_debugGetChunk(ZSTD_CCtx* c, size_t chunkIdx, ZSTDMI_Seq* seqs, siz
     *nbSeq = m.nbSeq; *litSize = m.litSize;
     const size_t ns = m.nbSeq < seqCap ? m.nbSeq : seqCap, nl = m.litSize < litCap ? m.litSize : litCap;
     if (ns && hipMemcpy(seqs, (Seq*)c->seqs.p + chunkIdx * kMaxSeq, ns * sizeof(Seq), hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
-    if (nl && hipMemcpy(lits, (u8*)c->lits.p + chunkIdx * kLitStride, nl, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
+    const u8* litDev = m.litFromSrc ? c->lastSrc + chunkIdx * (size_t)c->lastChunkBytes : (const u8*)c->lits.p + chunkIdx * kLitStride;
+    if (nl && (!litDev || hipMemcpy(lits, litDev, nl, hipMemcpyDeviceToHost) != hipSuccess)) return ZERR(kErrGeneric);
     return 0;
 }
 
@@ -987,8 +990,8 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (nbSeq) (void)hipMemcpyAsync(c->seqs.p, seqs, nbSeq * sizeof(Seq), hipMemcpyHostToDevice, s);
     if (litSize) (void)hipMemcpyAsync(c->lits.p, lits, litSize, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
-    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, 0, s);
-    launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, s);
+    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, 0, nullptr, 0, s);
+    launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, nullptr, 0, s);
     { const u32 plainReps[3] = { 1, 4, 8 };
       const Resolved rs = resolve_call(sticky_params(c), srcSize, kChunkSize);
       launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy, 0, 0, 0, 0, plainReps, s); }
