@@ -233,6 +233,7 @@ def main():
     ap.add_argument("--unique-mib", type=int, default=256, help="--mode decompress: distinct input the frames are built from (repeated up to --size-mib)")
     ap.add_argument("--level", type=int, default=1, help="compression level (BASELINE.json metric: 1; configs[3] uses 5)")
     ap.add_argument("--no-gather", action="store_true", help="N>1: skip the all-gather-v of compressed shards")
+    ap.add_argument("--gather-method", default="p2p", choices=["p2p", "padded"], help="N>1: exact-size grouped send/recv, or one padded all-gather + compaction")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
@@ -291,7 +292,7 @@ def main():
     stage_buf = out_buf = None
     step_no = 0
 
-    def step():
+    def step(gather=True):
         nonlocal gathered, step_no, stage_buf, out_buf
         b = step_no % len(dsts); step_no += 1
         buf = dsts[b]
@@ -299,16 +300,15 @@ def main():
             gather_done[b].synchronize()
         cs = lib.ZSTDMI_compressDevice(c.cctx, buf.data_ptr(), cap, src.data_ptr(), n)
         assert cs < (1 << 63), lib.ZSTD_getErrorName(cs)
-        if comm is not None:
+        if comm is not None and gather:
             from zstdsharp_amd.dist import all_gather_sizes, all_gather_v
             sizes = all_gather_sizes(cs, dev, group=pg_sizes)
-            pad = (max(sizes) + 4095) // 4096 * 4096
+            comm.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(comm):
-                if stage_buf is None or stage_buf.numel() < world * pad:
-                    stage_buf = torch.empty(world * pad + (64 << 20), dtype=torch.uint8, device=dev)
                 if out_buf is None or out_buf.numel() < sum(sizes):
                     out_buf = torch.empty(sum(sizes) + (64 << 20), dtype=torch.uint8, device=dev)
-                gathered = all_gather_v(buf, cs, sizes, out=out_buf, pad_to=pad, staging=stage_buf)
+                # exact-size grouped send/recv: every pair's bytes travel on that pair's own xGMI link, no padding, no compaction
+                gathered = all_gather_v(buf, cs, sizes, out=out_buf, method=args.gather_method)
                 ev = torch.cuda.Event(); ev.record(comm); gather_done[b] = ev
         r = lib.ZSTDMI_decompressDevice(d.dctx, back.data_ptr(), n, buf.data_ptr(), cs)
         assert r == n, lib.ZSTD_getErrorName(r)
@@ -339,6 +339,16 @@ def main():
         ok = ok and bool(torch.equal(gathered[:cs], last[:cs]))
     if dist is not None:
         t = torch.tensor([1 if ok else 0], device=dev); dist.all_reduce(t, op=dist.ReduceOp.MIN); ok = bool(t.item())
+    # N > 1: the collective-free number beside the gathered one (K more steps, outside the contract's timed region)
+    elapsed_ng = None
+    if comm is not None:
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather=False)
+        sync()
+        elapsed_ng = time.perf_counter() - t0
+        t = torch.tensor([elapsed_ng], dtype=torch.float64, device=dev); dist.all_reduce(t, op=dist.ReduceOp.MAX); elapsed_ng = float(t.item())
 
     if rank == 0:
         K = args.steps
@@ -356,9 +366,10 @@ def main():
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "config": {"workload": workload, "chunk": 65536, "framing": "one zstd frame per chunk",
-                       "gather": ("all-gather-v of compressed shards over RCCL on a side stream, overlapped with the decompress of its step and the compress of the next" if comm is not None else "none"),
+                       "gather": (f"all-gather-v of compressed shards over RCCL ({args.gather_method}) on a side stream, overlapped with the decompress of its step and the compress of the next" if comm is not None else "none"),
                        "parallelism": f"chunk-sharded x{world}"},
             "round_trip_bit_exact": ok, "ratio": round(ratio, 5),
+            "value_no_gather": (round(world * n / (elapsed_ng / K) / 1e6, 1) if elapsed_ng and ok else None),
             "compress_MBps_per_gpu": round(n / (t_comp * 1e-3) / 1e6, 1), "decompress_MBps_per_gpu": round(n / (t_dec * 1e-3) / 1e6, 1),
             "stage_ms": {k: round(v, 4) for k, v in allk.items()},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",

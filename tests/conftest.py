@@ -30,6 +30,18 @@ def golden():
 
 
 @pytest.fixture(scope="session")
+def golden_dict():
+    """libzstd-made dictionary / unsized / small-window fixtures (tests/golden/make_golden_dict.py); dictionaries as bytes"""
+    import json
+    d = os.path.join(ROOT, "tests", "golden")
+    man = json.load(open(os.path.join(d, "manifest_dict.json")))
+    for c in man["cases"]:
+        c["blob"] = open(os.path.join(d, c["file"]), "rb").read()
+        c["dict_bytes"] = open(os.path.join(d, c["dict"]), "rb").read() if c.get("dict") else None
+    return man["cases"]
+
+
+@pytest.fixture(scope="session")
 def gpu_lib():
     """The product library, bound through its C ABI.  Fails (not skips) if it cannot drive a GPU."""
     # torch first: the wheel bundles its own copy of the HIP runtime, and it cannot enumerate the GPU once the system

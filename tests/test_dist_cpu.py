@@ -10,22 +10,26 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def _worker(rank, world, port, total, q):
+def _worker(rank, world, port, total, q, cuts=None):
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from zstdsharp_amd.dist import shard_range, all_gather_sizes, all_gather_v
-    lo, hi = shard_range(total, rank, world)
     data = (torch.arange(total, dtype=torch.int64) * 7 % 251).to(torch.uint8)
+    # the shard every rank owns: the product's contiguous chunk ranges, or explicit uneven cuts (a zero-length shard included)
+    ranges = [shard_range(total, r, world) for r in range(world)] if cuts is None else [(cuts[r], cuts[r + 1]) for r in range(world)]
+    lo, hi = ranges[rank]
     # stand-in for "compress my shard": keep every third byte -> variable length per rank
     mine = data[lo:hi][::3].contiguous()
     buf = torch.zeros(hi - lo + 16, dtype=torch.uint8); buf[:mine.numel()] = mine
     sizes = all_gather_sizes(mine.numel(), "cpu")
-    pad = max(sizes)
-    if buf.numel() < pad:
-        buf = torch.cat([buf, torch.zeros(pad - buf.numel(), dtype=torch.uint8)])
-    out = all_gather_v(buf, mine.numel(), sizes)
-    expect = torch.cat([data[slice(*shard_range(total, r, world))][::3] for r in range(world)])
-    ok = bool(torch.equal(out, expect))
+    expect = torch.cat([data[a:b][::3] for a, b in ranges])
+    ok = True
+    for method in ("p2p", "padded"):
+        pad = max(max(sizes), 1)
+        if buf.numel() < pad:
+            buf = torch.cat([buf, torch.zeros(pad - buf.numel(), dtype=torch.uint8)])
+        out = all_gather_v(buf, mine.numel(), sizes, method=method)
+        ok = ok and bool(torch.equal(out, expect))
     # the bench's form: sizes on their own process group, caller-owned (oversized) staging and output buffers, padded slots
     pg = dist.new_group(backend="gloo")
     sizes2 = all_gather_sizes(mine.numel(), "cpu", group=pg)
@@ -33,8 +37,8 @@ def _worker(rank, world, port, total, q):
     if buf.numel() < pad2:
         buf = torch.cat([buf, torch.zeros(pad2 - buf.numel(), dtype=torch.uint8)])
     stage = torch.empty(world * pad2 + 1000, dtype=torch.uint8); outb = torch.empty(sum(sizes2) + 1000, dtype=torch.uint8)
-    for _ in range(2):                       # buffers are reused step after step
-        out2 = all_gather_v(buf, mine.numel(), sizes2, out=outb, pad_to=pad2, staging=stage)
+    for method in ("p2p", "padded", "p2p"):  # buffers are reused step after step
+        out2 = all_gather_v(buf, mine.numel(), sizes2, out=outb, pad_to=pad2, staging=stage, method=method)
         ok = ok and sizes2 == sizes and bool(torch.equal(out2, expect))
     q.put((rank, lo, hi, sizes, ok))
     dist.barrier(); dist.destroy_process_group()
@@ -61,4 +65,20 @@ def test_all_gather_v_world2_gloo():
     [p.join(60) for p in procs]
     assert res[0][1] == 0 and res[0][2] == res[1][1] and res[1][2] == total
     assert res[0][3] == res[1][3]
+    assert all(r[4] for r in res)
+
+
+def test_all_gather_v_world4_uneven_and_empty_shards_gloo():
+    """world 4, shards of very different sizes, one of them empty (a rank whose chunk range is empty when the input is short):
+    both exchange forms must give the rank-order concatenation."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    total = 700001
+    cuts = [0, 5, 5, 420000, total]                      # rank 1 owns nothing
+    procs = [ctx.Process(target=_worker, args=(r, 4, 29653, total, q, cuts)) for r in range(4)]
+    [p.start() for p in procs]
+    res = sorted(q.get(timeout=180) for _ in procs)
+    [p.join(60) for p in procs]
+    assert [r[1:3] for r in res] == [(0, 5), (5, 5), (5, 420000), (420000, total)]
+    assert res[1][3][1] == 0 and len(set(tuple(r[3]) for r in res)) == 1
     assert all(r[4] for r in res)

@@ -10,7 +10,7 @@ import pytest
 
 import datagen
 import zstdsharp_amd as z
-from zstdsharp_amd.errors import ZstdException
+from zstdsharp_amd.errors import ZSTD_ErrorCode, ZstdException
 from zstdsharp_amd.streams import CompressionStream, DecompressionStream
 
 pytestmark = pytest.mark.gpu
@@ -439,3 +439,49 @@ def test_formatted_dictionary_frames_on_every_literal_decoder(gpu_lib, oracle, m
                 assert d.Unwrap(frame) == data, (mode, n, k)
         assert treeless >= 6                                               # the dictionary's table really is in use
         assert d.Unwrap(blob) == b"".join(parts)
+
+
+def test_gpu_decoder_on_libzstd_dictionary_and_unsized_frames(gpu_lib, golden_dict):
+    """The GPU decoder on frames made by libzstd (not by this repo's oracle): ZDICT-trained formatted dictionary, raw-content
+    dictionary, unsized stream frames, windowLog 11 + checksum; each alone, all frames of one dictionary in one call, and through
+    DecompressionStream."""
+    import hashlib, io
+    from zstdsharp_amd.streams import DecompressionStream
+    for mode in (0, 1, 2, 3):
+        by_dict = {}
+        for c in golden_dict:
+            with z.Decompressor() as d:
+                assert gpu_lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, mode) == 0
+                if c["dict_bytes"]:
+                    d.LoadDictionary(c["dict_bytes"])
+                dest = bytearray(c["n"])                                   # exactly-sized destination, also for the unsized frames
+                assert d.Unwrap(c["blob"], dest) == c["n"], (mode, c["file"])
+                assert hashlib.sha256(bytes(dest)).hexdigest() == c["sha256"], (mode, c["file"])
+            by_dict.setdefault(c.get("dict"), []).append(c)
+        for dic, group in by_dict.items():
+            with z.Decompressor() as d:
+                assert gpu_lib.ZSTDMI_DCtx_setLiteralDecoder(d.dctx, mode) == 0
+                if dic:
+                    d.LoadDictionary(group[0]["dict_bytes"])
+                blob = b"".join(c["blob"] for c in group)
+                out = d.Unwrap(blob)
+                at = 0
+                for c in group:
+                    assert hashlib.sha256(out[at:at + c["n"]]).hexdigest() == c["sha256"], (mode, c["file"], "in one call")
+                    at += c["n"]
+                assert at == len(out)
+    # a frame that names the trained dictionary's ID, decoded without it or with another one: dictionary_wrong
+    fmt = [c for c in golden_dict if c.get("dict") == "trained_16k.dict"][2]
+    with z.Decompressor() as d:
+        with pytest.raises(ZstdException) as e:
+            d.Unwrap(fmt["blob"])
+        assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_dictionary_wrong
+    # streaming: the windowLog-11 frame passes the default windowLogMax, and is refused under windowLogMax = 10
+    w11 = [c for c in golden_dict if c.get("windowLog") == 11][0]
+    with DecompressionStream(io.BytesIO(w11["blob"]), 999) as ds:
+        assert hashlib.sha256(ds.ReadToEnd(4321)).hexdigest() == w11["sha256"]
+    with z.Decompressor() as d:
+        d.SetParameter(100, 10)
+        with pytest.raises(ZstdException) as e:
+            DecompressionStream(io.BytesIO(w11["blob"]), decompressor=d).ReadToEnd()
+        assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_frameParameter_windowTooLarge

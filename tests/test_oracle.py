@@ -197,3 +197,21 @@ def test_formatted_dictionary_frames(oracle):
             assert len(frame) < len(oracle.compress_dict(data, content, 1, 0)) < len(oracle.compress(data, 1, 0))
         assert oracle.decompress(oracle.compress(data, 1, 0), n, dic) == data        # dictionary-less frames decode with it loaded
     assert oracle.decompress(oracle.compress_dict(text(500, 5), dic, 1, 0), 500, dic[:40]) == -30      # truncated header: dictionary_corrupted
+
+
+def test_decoder_on_libzstd_dictionary_and_unsized_frames(oracle, golden_dict):
+    """Frames this repo did not make (tests/golden/make_golden_dict.py, libzstd 1.5.7): compressed against a ZDICT-trained
+    dictionary (formatted: its Huffman / FSE tables and repcodes are in use, the frames name its dictID) and against a raw-content
+    one, streamed without a pledged size (no content size in the header), and with windowLog 11 + checksum
+    (T/ZstdNetSteamingTests.cs:293).  The oracle decoder must regenerate every input bit-exactly."""
+    import hashlib
+    assert len(golden_dict) == 16
+    for c in golden_dict:
+        out = oracle.decompress(c["blob"], c["n"] + 64, c["dict_bytes"])
+        assert not isinstance(out, int), (c["file"], out)
+        assert len(out) == c["n"] and hashlib.sha256(out).hexdigest() == c["sha256"], c["file"]
+        if c.get("dict") == "trained_16k.dict":                      # these frames name the dictionary's ID: without it -> dictionary_wrong
+            assert c["blob"][4] & 3 != 0 and oracle.decompress(c["blob"], c["n"] + 64) == -32, c["file"]
+        if c.get("unsized"):
+            fhd = c["blob"][4]
+            assert fhd >> 6 == 0 and not (fhd >> 5) & 1, "no content size field, not single-segment"

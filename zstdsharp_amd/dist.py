@@ -29,22 +29,45 @@ def all_gather_sizes(nbytes: int, device, group=None) -> list:
 
 
 def all_gather_v(shard: torch.Tensor, nbytes: int, sizes: list, out: torch.Tensor = None, pad_to: int = None,
-                 staging: torch.Tensor = None):
+                 staging: torch.Tensor = None, method: str = "p2p", group=None):
     """All-gather variable-length byte shards.  Each rank contributes shard[:nbytes]; the result is the rank-order
-    concatenation (a uint8 tensor of sum(sizes) bytes).  Implemented as ONE padded all_gather_into_tensor (per-link
-    bound on xGMI, so one large collective beats G small ones) followed by a local compaction."""
-    world = dist.get_world_size()
-    pad = pad_to if pad_to is not None else max(sizes)
+    concatenation (a uint8 tensor of sum(sizes) bytes).
+
+    method "p2p" (default): exact sizes, no padding, no compaction — every rank posts one send per peer and one receive
+    per peer straight into that peer's offset of `out`, all in ONE group (ncclGroupStart/End under RCCL).  xGMI is a
+    point-to-point mesh (7 links per GPU): G - 1 concurrent pair transfers use every link at once, where a ring
+    all-gather moves all bytes over one link after the other.
+    method "padded": ONE all_gather_into_tensor of slots padded to `pad_to` (or max(sizes)) + one batched copy that
+    closes the gaps; kept for backends without grouped point-to-point."""
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    total = sum(sizes)
+    if out is None or out.numel() < total:
+        out = torch.empty(total, dtype=torch.uint8, device=shard.device)
+    offs = [0] * (world + 1)
+    for r, s in enumerate(sizes):
+        offs[r + 1] = offs[r] + s
+    assert sizes[rank] == nbytes, "sizes[] must hold what every rank contributes"
+    if method == "p2p":
+        ops = []
+        for step in range(1, world):                     # peer order rotated per rank: no link is asked twice at once
+            dst_r, src_r = (rank + step) % world, (rank - step) % world
+            if nbytes:
+                ops.append(dist.P2POp(dist.isend, shard[:nbytes], dst_r if group is None else dist.get_global_rank(group, dst_r), group))
+            if sizes[src_r]:
+                ops.append(dist.P2POp(dist.irecv, out[offs[src_r]:offs[src_r + 1]], src_r if group is None else dist.get_global_rank(group, src_r), group))
+        reqs = dist.batch_isend_irecv(ops) if ops else []
+        if nbytes:
+            out[offs[rank]:offs[rank + 1]].copy_(shard[:nbytes])
+        for q in reqs:
+            q.wait()
+        return out[:total]
+    pad = pad_to if pad_to is not None else max(max(sizes), 1)
     assert shard.numel() >= pad, "the shard buffer must be at least as large as the padded slot"
     if staging is None or staging.numel() < world * pad:
         staging = torch.empty(world * pad, dtype=torch.uint8, device=shard.device)
     staging = staging[:world * pad]
-    dist.all_gather_into_tensor(staging, shard[:pad].contiguous())
-    total = sum(sizes)
-    if out is None or out.numel() < total:
-        out = torch.empty(total, dtype=torch.uint8, device=shard.device)
-    off = 0
-    for r, s in enumerate(sizes):
-        out[off:off + s] = staging[r * pad:r * pad + s]
-        off += s
+    dist.all_gather_into_tensor(staging, shard[:pad].contiguous(), group=group)
+    if total:
+        torch.cat([staging[r * pad:r * pad + s] for r, s in enumerate(sizes) if s], out=out[:total])    # one batched copy
     return out[:total]
