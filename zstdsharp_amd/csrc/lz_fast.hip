@@ -12,8 +12,9 @@
 //            ZstdFast.cs:179-191); periods 1..4 (runs) are tested in registers; the lazy finder lets a match yield to the
 //            one starting a byte later (gain rule of U/ZstdLazy.cs:1836-1870);
 //   select   the greedy left-to-right parse "next = first match at or after the end of the current one" is the orbit
-//            of a jump function over the tile: tiles with <= 64 matches are walked by wave 0, dense tiles by pointer
-//            doubling with all 1024 lanes (J -> J^4 per round, double-buffered, one barrier per round);
+//            of a jump function over the tile: tiles with <= 64 matches are walked by wave 0; in dense tiles every wave
+//            turns its 256 positions into an entry -> exit function (pointer doubling in registers, by shuffles), the
+//            sixteen functions are chained after one barrier and every wave marks its own part of the orbit;
 //   finish   matches that hit the 32-byte cap are completed by wave 0 with 64 lanes x 8 bytes per step, in order,
 //            dropping the selections they swallow;
 //   emit     every selected match computes its own sequence in parallel (rank by popcount prefix, literal length from
@@ -47,8 +48,6 @@ constexpr u32 kTileLog  = 12;
 constexpr u32 kGroups   = kTilePos / 64; // 64-position groups per tile
 constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; capped matches are finished by wave 0
 constexpr u32 kInPad    = 64;
-constexpr u32 kExit     = 0xFFFFu;       // jump target "leaves the tile"
-constexpr u32 kHop      = 4;             // orbit rounds compose the jump function kHop-fold
 static_assert((1u << kTileLog) == kTilePos && kGroups == 64, "tile geometry");
 
 struct LzLds {
@@ -135,19 +134,6 @@ __device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w,
     if (l > n - p) l = n - p;
     if (l > kLenCap) l = kLenCap;
     return l >= 4 ? l : 0;
-}
-
-// first match position >= c inside the tile (tile-relative), or kExit
-__device__ __forceinline__ u32 next_match(const LzLds& L, u32 c, u32 par)
-{
-    if (c >= kTilePos) return kExit;
-    const u32 wi = c >> 6;
-    const u64 w = L.matchMask[wi] >> (c & 63);
-    if (w) return c + ctz64(w);
-    const u64 rest = wi + 1 < kGroups ? (L.nzWords[par] >> (wi + 1)) : 0;
-    if (!rest) return kExit;
-    const u32 wj = wi + 1 + ctz64(rest);
-    return wj * 64 + ctz64(L.matchMask[wj]);
 }
 
 // MODE 0 = fast strategy (one 6-byte hash; levels 1-2 and the negative levels); 1 = doubleFast strategy (8-byte + SHORT-byte
@@ -495,56 +481,75 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         const bool any = matchCount != 0 && c0 < span;                   // uniform
         const bool dense = any && matchCount > 64 && !super;
         if (dense) {
-            // ---------------- select: orbit of the greedy parse by pointer doubling ----------------
-            u16* cur = L.jump; u16* nxt = L.jumpB;
-            bool has[kPPT];
+            // ---------------- select: the orbit of the greedy parse, segment by segment ----------------
+            // The parse is the orbit of "next match at or after the end of this one" from the entry cursor.  A segment is 64
+            // positions, a wave owns four consecutive ones (lane = position inside the segment).  Because a match is at most
+            // kLenCap = 32 long here, the cursor enters a segment at one of its first 32 positions, so a segment IS a function
+            // entry offset -> exit offset (into the next segment).  Each wave computes it for all entries at once by pointer
+            // doubling in registers (five shuffle rounds: a step advances by >= 4 from a match, 2^5 steps leave the segment),
+            // composes its four segments, and publishes 32 bytes.  After ONE barrier every wave chains the functions of the
+            // waves before it (readlane on values held in registers), then walks its own segments from the now known entry
+            // with the single-step jumps: at most 16 matches per segment, a readlane each.
+            u8* const segFn = reinterpret_cast<u8*>(L.jumpB + 3072);          // [16][32]; behind endOf (u32[1026]) inside jumpB
+            u32* const segExit0 = reinterpret_cast<u32*>(L.jumpB + 3072 + 256);
+            const u32 w0 = c0 >> 8, k0 = (c0 >> 6) & 3u, e0 = c0 & 63u;       // (uniform) where the entry cursor sits
+            u32 J1[4], X[4]; u64 mmS[4];
 #pragma unroll
-            for (u32 j = 0; j < kPPT; ++j) {
-                const u32 q = j * kTile + tid;
-                has[j] = (L.matchMask[q >> 6] >> (q & 63)) & 1ull;
-                if (has[j]) cur[q] = (u16)next_match(L, q + L.tileLen[q], par);
+            for (u32 k = 0; k < 4; ++k) {
+                const u32 g = wave * 4 + k;
+                const u64 mmv = L.matchMask[g];
+                const u64 mm = (u64)uniform((u32)mmv) | ((u64)uniform((u32)(mmv >> 32)) << 32);
+                mmS[k] = mm;
+                const bool has = (mm >> lane) & 1ull;
+                const u32 len = has ? (u32)L.tileLen[g * 64 + lane] : 0u;
+                const u32 t = lane + len;                                     // a match: its end; no match here: the cursor itself
+                u32 j = t;                                                    // >= 64: leaves the segment at offset t - 64 (< 32)
+                if (t < 64) { const u64 rest = mm >> t; j = rest ? t + ctz64(rest) : 64u; }
+                J1[k] = j; X[k] = j;
             }
-            const u32 s0 = next_match(L, c0, par);                       // uniform: first match at or after the entry cursor
-            if (tid == 0 && s0 != kExit) L.selMask[s0 >> 6] = 1ull << (s0 & 63);
-            __syncthreads();
-            // Each round replaces J by J^4 (double-buffered, one barrier) and lets every selected position mark J, J^2, J^3
-            // of itself: after r rounds the orbit points of index < 4^r are marked, and J^(4^r)(s0) leaving the tile ends it.
-            if (s0 != kExit) {
-                for (u32 round = 0; round < kTileLog; ++round) {
-                    // the hops of the thread's four positions are independent chains of LDS reads: written hop-major and
-                    // branch-free so that the four reads of a hop are in flight together; marks come afterwards
-                    u32 a[kPPT][kHop]; bool isSel[kPPT];
 #pragma unroll
-                    for (u32 j = 0; j < kPPT; ++j) {
-                        const u32 q = j * kTile + tid;
-                        isSel[j] = has[j] && ((L.selMask[q >> 6] >> (q & 63)) & 1ull);
-                        a[j][0] = has[j] ? (u32)cur[q] : kExit;
+            for (u32 r = 0; r < 5; ++r) {
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) { const u32 nx = (u32)__shfl((int)X[k], (int)(X[k] & 63u)); X[k] = X[k] < 64 ? nx : X[k]; }
+            }
+            {   // the wave's four segments composed: entry offset (lane, < 32) -> exit offset into the next wave's first segment
+                u32 y = X[0] - 64;
+#pragma unroll
+                for (u32 k = 1; k < 4; ++k) y = (u32)__shfl((int)X[k], (int)y) - 64;
+                if (lane < 32) segFn[wave * 32 + lane] = (u8)y;
+                if (wave == w0) {                                             // (uniform) the wave the entry cursor falls into: from segment k0, offset e0
+                    u32 z = 0;
+#pragma unroll
+                    for (u32 k = 0; k < 4; ++k) {
+                        if (k == k0) z = read_lane(X[k], e0) - 64;
+                        else if (k > k0) z = read_lane(X[k], z) - 64;
                     }
-#pragma unroll
-                    for (u32 hop = 1; hop < kHop; ++hop) {
-#pragma unroll
-                        for (u32 j = 0; j < kPPT; ++j) {
-                            const u32 pv = a[j][hop - 1];
-                            const u32 nx = cur[pv != kExit ? pv : 0];
-                            a[j][hop] = pv != kExit ? nx : kExit;
-                        }
-                    }
-#pragma unroll
-                    for (u32 j = 0; j < kPPT; ++j) {
-                        if (isSel[j]) {
-#pragma unroll
-                            for (u32 hop = 0; hop + 1 < kHop; ++hop) {
-                                const u32 t = a[j][hop];
-                                if (t != kExit) atomicOr((unsigned long long*)&L.selMask[t >> 6], (unsigned long long)(1ull << (t & 63)));
-                            }
-                        }
-                        if (has[j]) nxt[j * kTile + tid] = (u16)a[j][kHop - 1];
-                    }
-                    __syncthreads();
-                    { u16* t_ = cur; cur = nxt; nxt = t_; }
-                    if (cur[s0] == kExit) break;
+                    if (lane == 0) *segExit0 = z;
                 }
             }
+            __syncthreads();
+            if (wave >= w0) {                                                 // (uniform) earlier waves lie before the cursor: nothing selected
+                u32 ent = e0, kStart = k0;
+                if (wave > w0) {
+                    u32 fv[16];
+#pragma unroll
+                    for (u32 k = 0; k < 16; ++k) fv[k] = segFn[k * 32 + (lane & 31u)];
+                    ent = uniform(*segExit0); kStart = 0;
+#pragma unroll
+                    for (u32 k = 1; k < 15; ++k) if (k > w0 && k < wave) ent = read_lane(fv[k], ent);
+                }
+#pragma unroll
+                for (u32 k = 0; k < 4; ++k) {
+                    if (k < kStart) continue;                                 // uniform
+                    const u64 rest = mmS[k] >> ent;
+                    u32 p = rest ? ent + ctz64(rest) : 64u;
+                    u64 mark = 0;
+                    while (p < 64) { mark |= 1ull << p; p = read_lane(J1[k], p); }
+                    ent = p - 64;
+                    if (lane == 0) L.selMask[wave * 4 + k] = mark;
+                }
+            }
+            __syncthreads();
             ZMI_STAMP(8);
             if (wave == 0) {
                 // ---- finish capped matches in order; drop the selections they swallow ----
