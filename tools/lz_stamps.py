@@ -25,7 +25,7 @@ for kind in ("zipf", "text"):
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     raw.ZSTDMI_debugReadLzStamps(buf, 1)
     tot = sum(buf[i] for i in range(8)); chunks = n // 65536
-    print(kind, "lz cycles/chunk", tot // chunks, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(10)}, flush=True)
+    print(kind, "lz wave-cycles/chunk/16", (tot + buf[8] + buf[9]) // chunks // 16, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(10)}, flush=True)
     raw.ZSTDMI_debugReadHufStamps(buf, 1)
     tot = sum(buf[i] for i in range(8))
     print(kind, "huf_build cycles/chunk", tot // chunks, {hnames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)

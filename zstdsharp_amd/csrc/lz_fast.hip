@@ -35,7 +35,7 @@ namespace zmi {
 #ifdef ZMI_LZ_STAMPS
 // diagnostic build only (make STAMPS=1): per-phase shader-clock sums of thread 0 of every workgroup
 __device__ unsigned long long g_lzStamps[16];
-#define ZMI_STAMP(i) do { if (tid == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
+#define ZMI_STAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
 #else
 #define ZMI_STAMP(i) do { } while (0)
 #endif
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
-    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
+    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = uniform(wave_id());
     // Raw-content dictionary (row f-4; ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5126-5237): its last `prefixLen` bytes
     // sit in front of the chunk in LDS, ending at a tile boundary (hist = whole tiles of history, positions below lowLimit
     // are padding and never referenced).  History tiles run the probe/insert half of the loop only; the parse starts
@@ -490,8 +490,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             // composes its four segments, and publishes 32 bytes.  After ONE barrier every wave chains the functions of the
             // waves before it (readlane on values held in registers), then walks its own segments from the now known entry
             // with the single-step jumps: at most 16 matches per segment, a readlane each.
-            u8* const segFn = reinterpret_cast<u8*>(L.jumpB + 3072);          // [16][32]; behind endOf (u32[1026]) inside jumpB
-            u32* const segExit0 = reinterpret_cast<u32*>(L.jumpB + 3072 + 256);
+            u8* const segFn = reinterpret_cast<u8*>(L.jumpB + 3584);          // [16][32]; jumpB holds: endOf u32[1026] | selPos u16[1024] at 2304 | segFn
+            u32* const segExit0 = reinterpret_cast<u32*>(L.jumpB + 3584 + 256);
+            u16* const selPos = L.jumpB + 2304;
             const u32 w0 = c0 >> 8, k0 = (c0 >> 6) & 3u, e0 = c0 & 63u;       // (uniform) where the entry cursor sits
             u32 J1[4], X[4]; u64 mmS[4];
 #pragma unroll
@@ -586,23 +587,25 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
             __syncthreads();
             ZMI_STAMP(9);
-            u32 myRank[kPPT], myEnd[kPPT]; bool sel[kPPT];
+            // every selected match files its position and its end under its rank; after the barrier the matches are emitted BY RANK,
+            // one per lane from lane 0 up (a tile selects a few hundred of its 4096 positions: emitting by position would run the
+            // emission code sixty-four times per thread row with a handful of lanes active)
 #pragma unroll
             for (u32 j = 0; j < kPPT; ++j) {
                 const u32 q = j * kTile + tid;
                 const u64 sm = L.selMask[q >> 6];
-                sel[j] = (sm >> (q & 63)) & 1ull;
-                myRank[j] = 0; myEnd[j] = 0;
-                if (sel[j]) {
-                    myRank[j] = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
+                if ((sm >> (q & 63)) & 1ull) {
+                    const u32 rank = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
                     const u32 len = L.tileLen[q];
-                    myEnd[j] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
-                    endOf[myRank[j] + 1] = myEnd[j];
+                    endOf[rank + 1] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
+                    selPos[rank] = (u16)q;
                 }
             }
             __syncthreads();
-#pragma unroll
-            for (u32 j = 0; j < kPPT; ++j) if (sel[j]) emit_match(tileStart, j * kTile + tid, j * kTile + tid, myRank[j], myEnd[j]);
+            {
+                const u32 nSelT = L.wordRank[64];
+                if (tid < nSelT) { const u32 q = selPos[tid]; emit_match(tileStart, q, q, tid, endOf[tid + 1]); }
+            }
         } else if (any) {
             // ---------------- sparse tile (<= 64 matches) or super-tile: wave 0 parses it alone, exactly greedy ----------------
             // (a super-tile may hold more than 64 matches: they are walked 64 at a time, at most kSuperMax of them — the
@@ -731,7 +734,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(7);
     }
 #ifdef ZMI_LZ_STAMPS
-    if (tid == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
+    if ((tid & 63u) == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
 #endif
     if (tid == 0) {
         ChunkMeta m = {};
