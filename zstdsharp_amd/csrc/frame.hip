@@ -77,13 +77,17 @@ __device__ __forceinline__ u64 rotl64(u64 x, int r) { return (x << r) | (x >> (6
 __device__ __forceinline__ u64 xxh_round(u64 acc, u64 in) { acc += in * P2; acc = rotl64(acc, 31); return acc * P1; }
 __device__ __forceinline__ u64 xxh_merge(u64 acc, u64 v) { acc ^= xxh_round(0, v); return acc * P1 + P4; }
 
-__global__ __launch_bounds__(256) void xxh64_kernel(const u8* __restrict__ src, u64 srcSize, ChunkMeta* __restrict__ meta, u32 nChunks, u32 chunkBytes)
+// (one frame = frameBlocks chunks of chunkBytes; the checksum is filed with the frame's last block, which carries it)
+__global__ __launch_bounds__(256) void xxh64_kernel(const u8* __restrict__ src, u64 srcSize, ChunkMeta* __restrict__ meta, u32 nChunks, u32 chunkBytes,
+                                                    u32 frameBlocks)
 {
     const u32 t = blockIdx.x * 256 + threadIdx.x;
-    const u32 c = t >> 2, j = t & 3;
-    if (c >= nChunks) return;           // whole groups of 4 lanes leave together
-    const u64 base = (u64)c * chunkBytes;
-    const u32 n = (u32)((srcSize - base) < chunkBytes ? (srcSize - base) : chunkBytes);
+    const u32 f = t >> 2, j = t & 3;
+    if ((u64)f * frameBlocks >= nChunks) return;           // whole groups of 4 lanes leave together
+    const u64 frameBytes = (u64)frameBlocks * chunkBytes;
+    const u64 base = (u64)f * frameBytes;
+    const u32 n = (u32)((srcSize - base) < frameBytes ? (srcSize - base) : frameBytes);
+    const u32 c = (f + 1) * frameBlocks <= nChunks ? (f + 1) * frameBlocks - 1 : nChunks - 1;
     const u8* p = src + base;
     u64 h;
     const u32 stripes = n >> 5;
@@ -114,9 +118,11 @@ void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta*
 {
     hipLaunchKernelGGL(gather_kernel, dim3(nChunks), dim3(256), 0, stream, src, srcSize, slots, meta, offsets, dst, dstCapacity, chunkBytes);
 }
-void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, hipStream_t stream)
+void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, u32 frameBlocks, hipStream_t stream)
 {
-    hipLaunchKernelGGL(xxh64_kernel, dim3((nChunks * 4 + 255) / 256), dim3(256), 0, stream, src, srcSize, meta, nChunks, chunkBytes);
+    if (!frameBlocks) frameBlocks = 1;
+    const u32 nFrames = (nChunks + frameBlocks - 1) / frameBlocks;
+    hipLaunchKernelGGL(xxh64_kernel, dim3((nFrames * 4 + 255) / 256), dim3(256), 0, stream, src, srcSize, meta, nChunks, chunkBytes, frameBlocks);
 }
 
 } // namespace zmi

@@ -144,8 +144,8 @@ template <int MODE, int SHORT, bool DICT>
 __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
-                                                  const u8* __restrict__ prefix, const u32 prefixLen, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog)
+                                                  const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -155,12 +155,19 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // are padding and never referenced).  History tiles run the probe/insert half of the loop only; the parse starts
     // with the cursor at `hist`, so everything after it is untouched: offsets simply reach back into the history.
     // chunkBytes = 64 KiB - hist (64 KiB without a dictionary).
-    const u32 hist = DICT ? kChunkSize - chunkBytes : 0u, lowLimit = DICT ? hist - prefixLen : 0u;
+    // Cross-chunk history (row f-1; the block loop's window, U/ZstdCompress.cs:4705-4807): frameBlocks > 0 makes every
+    // `frameBlocks` consecutive chunks the blocks of ONE frame, and a block's history is the input in front of it — up to
+    // `hist` bytes, as far back as its frame reaches — staged in the same place a dictionary's tail would be.
     const u32 cb = DICT ? chunkBytes : kChunkSize;
+    const u32 hist = DICT ? kChunkSize - chunkBytes : 0u;
     const u64 base = (u64)c * cb;
+    const u8* __restrict__ in = src + base;
+    const u32 bf = (DICT && frameBlocks) ? c % frameBlocks : 0u;                       // block index inside its frame
+    u32 prefixLen = prefixLenArg; const u8* __restrict__ prefix = prefixArg;
+    if (DICT && frameBlocks) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
+    const u32 lowLimit = DICT ? hist - prefixLen : 0u;
     const u32 nData = (u32)((srcSize - base) < cb ? (srcSize - base) : cb);
     const u32 n = hist + nData;                            // end of the data in LDS
-    const u8* __restrict__ in = src + base;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
@@ -183,7 +190,14 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     } else {
         for (u32 i = tid; i < nData; i += kTile) L.in[hist + i] = in[i];
     }
-    if (DICT) for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
+    if (DICT) {
+        if (frameBlocks && ((((uintptr_t)prefix) | lowLimit) & 15) == 0) {                  // the input in front of the block: 16 bytes per lane
+            const uint4* p4 = reinterpret_cast<const uint4*>(prefix);
+            uint4* l4 = reinterpret_cast<uint4*>(L.in + lowLimit);
+            for (u32 i = tid; i < (prefixLen >> 4); i += kTile) l4[i] = p4[i];
+            for (u32 i = tid; i < lowLimit; i += kTile) L.in[i] = 0;
+        } else for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
+    }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     u32* const endOf = reinterpret_cast<u32*>(L.jumpB);
     u32* const table = L.tabMem;                           // fast
@@ -273,7 +287,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     u32 prevStride = 0;                  // the previous iteration's stride
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
-    for (u32 t = 0, it = 0; t < nTiles; ++it) {
+    for (u32 t = lowLimit >> kTileLog, it = 0; t < nTiles; ++it) {      // (tiles wholly below lowLimit are padding)
         const u32 tileStart = t * kTilePos;
         const bool histTile = DICT && tileStart < hist;                                         // uniform: dictionary bytes, insert only
         // stride: every 2nd / 4th position after a sparse tile; where a strided iteration found next to nothing either, every
@@ -738,7 +752,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #endif
     if (tid == 0) {
         ChunkMeta m = {};
-        m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase; m.fhSize = frame_header_size(nData) + fhExtra;      // fhExtra: bytes of the dictID field (formatted dictionary), else 0
+        m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase;
+        if (DICT && frameBlocks) {            // only a frame's first block carries the frame header, sized for the whole frame's content
+            const u64 fStart = base - (u64)bf * cb, fMax = (u64)frameBlocks * cb;
+            const u64 fLen = (srcSize - fStart) < fMax ? (srcSize - fStart) : fMax;
+            m.fhSize = bf == 0 ? frame_header_size64(fLen) + fhExtra : 0u;
+        } else m.fhSize = frame_header_size(nData) + fhExtra;      // fhExtra: bytes of the dictID field (formatted dictionary), else 0
         m.litFromSrc = deferred ? 1u : 0u;       // (then nbSeq = 0 and litBase = nData: the literals are the chunk itself)
         meta[c] = m;
     }
@@ -756,7 +775,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream)
 {
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
@@ -765,28 +784,29 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
 // minMatch at levels 4+, was measured and lost ratio on every corpus tried: far 4-byte matches cost more than literals.)
 // prefix/prefixLen: the dictionary bytes every chunk sees as history (null/0 without one); chunkBytes = 64 KiB minus prefixLen
-// rounded up to whole 4 KiB tiles.
+// rounded up to whole 4 KiB tiles.  frameBlocks > 0: cross-chunk history instead (no dictionary): `frameBlocks` chunks of chunkBytes
+// form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream)
 {
-    if (prefixLen == 0 || chunkBytes >= kChunkSize) {
+    if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, stream); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, stream); break;
     }
 }
 

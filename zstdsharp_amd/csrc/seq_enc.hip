@@ -161,7 +161,8 @@ __device__ __forceinline__ u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count
 
 __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs, ChunkMeta* __restrict__ meta,
                                                          u8* __restrict__ slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
-                                                         u32 dictID, u32 dictIdBytes, u32 initRep0, u32 initRep1, u32 initRep2)
+                                                         u32 dictID, u32 dictIdBytes, u32 initRep0, u32 initRep1, u32 initRep2,
+                                                         const u32 frameBlocks, const u32 chunkBytes, const u64 srcSize)
 {
     __shared__ SeqWaveLds Ws[4];
     const u32 lane = lane_id(), wave = wave_id();
@@ -170,6 +171,19 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     SeqWaveLds& W = Ws[wave];
     ChunkMeta m = meta[c];
     const u32 nbSeq = m.nbSeq, n = m.srcSize;
+    // Multi-block frames (row f-1): chunk c is block bf of frame c / frameBlocks.  A later block never relies on the repcodes the
+    // blocks before it leave behind — whether one of them ends up stored raw (and so leaves the decoder's history untouched,
+    // U/ZstdCompress.cs:3620-3640) is only known once it has been encoded — so its history starts as "unknown" (0 matches no
+    // offset): offsets are written in full until the block itself has defined the repcode they would use.  That is always a
+    // valid encoding (the decoder pushes a full offset whatever it equals) and costs a few bits per block.
+    const u32 bf = frameBlocks ? c % frameBlocks : 0u;
+    u64 frameLen = n; bool lastBlock = true;
+    if (frameBlocks) {
+        const u64 fStart = (u64)(c - bf) * chunkBytes, fMax = (u64)frameBlocks * chunkBytes;
+        frameLen = (srcSize - fStart) < fMax ? (srcSize - fStart) : fMax;
+        lastBlock = (u64)(bf + 1) * chunkBytes >= frameLen;
+        if (bf) { initRep0 = 0; initRep1 = 0; initRep2 = 0; }
+    }
     Seq* __restrict__ sq = seqs + (u64)c * kMaxSeq;
     u8* const slot = slots + (u64)c * kSlotStride;
     u8* const body = slot + m.fhSize + 3;
@@ -365,35 +379,37 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     u32 cSize = (u32)(op - body);
     if (!giveUp && cSize >= n - ((n >> 6) + 2)) giveUp = true;                      // ZSTD_minGain
 
-    // ---- frame header (single segment, content size known) ----
-    {
-        const u32 fcsCode = (n >= 256) + (n >= 65536 + 256);
+    // ---- frame header (single segment, content size known), in front of the frame's first block ----
+    if (bf == 0) {
+        const u32 fcsCode = (frameLen >= 256) + (frameLen >= 65536 + 256) + (frameLen > 0xFFFFFFFFull);
         writeLE32(slot, 0xFD2FB528u);
         const u32 didCode = dictIdBytes == 4 ? 3u : dictIdBytes;          // dictID field of 0, 1, 2 or 4 bytes (U/ZstdCompress.cs:4843-4849, 4896-4918)
         slot[4] = (u8)(didCode + ((checksumFlag ? 1u : 0u) << 2) + (1u << 5) + (fcsCode << 6));
         for (u32 i = 0; i < dictIdBytes; i++) slot[5 + i] = (u8)(dictID >> (8 * i));
         u8* const fcs = slot + 5 + dictIdBytes;
-        if (fcsCode == 0) fcs[0] = (u8)n;
-        else if (fcsCode == 1) writeLE16(fcs, n - 256);
-        else writeLE32(fcs, n);
+        if (fcsCode == 0) fcs[0] = (u8)frameLen;
+        else if (fcsCode == 1) writeLE16(fcs, (u32)frameLen - 256);
+        else if (fcsCode == 2) writeLE32(fcs, (u32)frameLen);
+        else { writeLE32(fcs, (u32)frameLen); writeLE32(fcs + 4, (u32)(frameLen >> 32)); }
     }
     u8* const bh = slot + m.fhSize;
+    const u32 lastBit = lastBlock ? 1u : 0u;                  // Last_Block (U/ZstdCompress.cs:4757-4760)
     if (giveUp) {            // ZSTD_noCompressBlock: the gather kernel copies the n source bytes behind this header
-        writeLE24(bh, 1u + (0u << 1) + (n << 3));
+        writeLE24(bh, lastBit + (0u << 1) + (n << 3));
         m.blockType = 0; m.bodySize = 0; cSize = n;
     } else {
-        writeLE24(bh, 1u + (2u << 1) + (cSize << 3));
+        writeLE24(bh, lastBit + (2u << 1) + (cSize << 3));
         m.blockType = 2; m.bodySize = cSize;
     }
-    m.outSize = m.fhSize + 3 + cSize + (checksumFlag ? 4 : 0);
+    m.outSize = m.fhSize + 3 + cSize + ((checksumFlag && lastBlock) ? 4 : 0);
     meta[c] = m;
 }
 
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
-                       u32 dictID, u32 dictIdBytes, const u32* initReps, hipStream_t stream)
+                       u32 dictID, u32 dictIdBytes, const u32* initReps, u32 frameBlocks, u32 chunkBytes, u64 srcSize, hipStream_t stream)
 {
     hipLaunchKernelGGL(seq_encode_kernel, dim3((nChunks + 3) / 4), dim3(256), 0, stream, seqs, meta, slots, nChunks, strategy, checksumFlag, resolveReps,
-                       dictID, dictIdBytes, initReps[0], initReps[1], initReps[2]);
+                       dictID, dictIdBytes, initReps[0], initReps[1], initReps[2], frameBlocks, chunkBytes, srcSize);
 }
 
 #ifdef ZMI_LZ_STAMPS

@@ -55,5 +55,6 @@ __device__ __forceinline__ void writeLE32(u8* p, u32 v) { p[0] = (u8)v; p[1] = (
 
 // frame header size for a chunk of n bytes: magic + FHD + FCS, single-segment (U/ZstdCompress.cs:4817-4929)
 __host__ __device__ __forceinline__ u32 frame_header_size(u32 n) { return 4 + 1 + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : 4)); }
+__host__ __device__ __forceinline__ u32 frame_header_size64(u64 n) { return 4 + 1 + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : (n <= 0xFFFFFFFFull ? 4 : 8))); }
 
 } // namespace zmi

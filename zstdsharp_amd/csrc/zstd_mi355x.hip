@@ -18,17 +18,17 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, const u8* src, u32 chunkBytes, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
-                       u32 dictID, u32 dictIdBytes, const u32* initReps, hipStream_t stream);
+                       u32 dictID, u32 dictIdBytes, const u32* initReps, u32 frameBlocks, u32 chunkBytes, u64 srcSize, hipStream_t stream);
 void launch_scan_sizes(const ChunkMeta* meta, u32 nChunks, u64* offsets, u64* total, hipStream_t stream);
 void launch_gather(const u8* src, u64 srcSize, const u8* slots, const ChunkMeta* meta, const u64* offsets, u8* dst, u64 dstCapacity,
                    u32 nChunks, u32 chunkBytes, hipStream_t stream);
-void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, hipStream_t stream);
+void launch_xxh64(const u8* src, u64 srcSize, ChunkMeta* meta, u32 nChunks, u32 chunkBytes, u32 frameBlocks, hipStream_t stream);
 // decoder (decode_walk.hip, decode_lit.hip, decode_seq.hip)
 size_t decode_walk_workspace_bytes(u64 srcSize);
 void launch_frame_walk_count(const u8* src, u64 srcSize, u32 maxFrames, u32* status, u8* walkWs, hipStream_t stream);
@@ -123,6 +123,9 @@ struct ZSTD_CCtx_s {
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
     const u8* lastSrc = nullptr; u32 lastChunkBytes = 0;     // its source (debug hook: chunks without sequences keep their literals there)
     u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
+    // cross-chunk history (row f-1): -1 = by level (on for the strategies above fast, i.e. levels >= 3, and whenever the caller
+    // asks for a windowLog above 16), 0 = off (independent 64 KiB frames), else the bytes of history per block (4 KiB units)
+    int historyBytes = -1; u32 frameBytes = 256u << 10;
     // streaming adapter (ZSTD_compressStream2): host-side batching in front of the one-shot engine
     std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
     StageTimer timer;
@@ -195,13 +198,13 @@ static size_t dctx_bind(ZSTD_DCtx* d)
 // ZSTD_compressCCtx, the level alone with default frame parameters and no dictionary (U/ZstdCompress.cs:5751-5776:
 // compress_usingDict(NULL) builds its parameters from the level and leaves the context's requested ones untouched).
 struct CallParams {
-    int level = 3, checksumFlag = 0, dictIDFlag = 1, strategy = 0, targetLength = 0;
+    int level = 3, checksumFlag = 0, dictIDFlag = 1, strategy = 0, targetLength = 0, windowLog = 0;
     bool useDict = true;
 };
 static CallParams sticky_params(const ZSTD_CCtx* c)
 {
     CallParams p; p.level = c->level; p.checksumFlag = c->checksumFlag; p.dictIDFlag = c->dictIDFlag;
-    p.strategy = c->strategy; p.targetLength = c->targetLength; p.useDict = true;
+    p.strategy = c->strategy; p.targetLength = c->targetLength; p.windowLog = c->windowLog; p.useDict = true;
     return p;
 }
 
@@ -281,17 +284,34 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
     }
     if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
     const u32 prefixLen = cp.useDict ? dict_prefix_len(c, srcSize) : 0u;
-    const u32 chunkBytes = kChunkSize - round_tile(prefixLen);
+    u32 chunkBytes = kChunkSize - round_tile(prefixLen);
     // a formatted dictionary: its dictID in every frame header (unless ZSTD_c_dictIDFlag = 0), its repcodes in front of every frame
     const bool fmtDict = cp.useDict && c->dictFormatted;
     const u32 dictID = fmtDict ? c->info.dictID : 0u;
     const u32 dictIdBytes = (dictID && cp.dictIDFlag) ? (dictID < 256 ? 1u : dictID < 65536 ? 2u : 4u) : 0u;
     const u32 plainReps[3] = { 1, 4, 8 };
     const u32* const initReps = fmtDict ? c->info.rep : plainReps;
-    const Resolved rs = resolve_call(cp, srcSize, chunkBytes);
+    Resolved rs = resolve_call(cp, srcSize, chunkBytes);
+    // Cross-chunk history (the window the block loop carries, U/ZstdCompress.cs:4705-4807): blocks of 64 KiB - hist
+    // bytes, each with the hist bytes in front of it as match-only history in LDS, frameBlocks of them to a frame (so a
+    // match never reaches out of its frame and frames stay independent units for the decoder and for sharding).  Without a
+    // dictionary only (a dictionary's tail takes the same place in LDS).
+    u32 frameBlocks = 0;
+    if (prefixLen == 0 && srcSize > kChunkSize) {
+        int hb = c->historyBytes;
+        if (hb < 0) hb = (rs.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (32 << 10) : 0;
+        if (hb > 0) {
+            const u32 histB = round_tile((size_t)hb) > (48u << 10) ? (48u << 10) : round_tile((size_t)hb);
+            chunkBytes = kChunkSize - histB;
+            frameBlocks = c->frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
+            const u64 frameLen = (u64)frameBlocks * chunkBytes;
+            rs = resolve_call(cp, srcSize < frameLen ? srcSize : frameLen, (u32)frameLen);
+        }
+    }
     const u8* prefix = prefixLen ? (const u8*)c->dict.p + (c->dictHost.size() - prefixLen) : nullptr;
     const u64 totalChunks = (srcSize + chunkBytes - 1) / chunkBytes;
-    const u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
+    u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
+    if (frameBlocks && passChunks < totalChunks) { passChunks -= passChunks % frameBlocks; if (!passChunks) passChunks = frameBlocks; }     // frames never straddle passes
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy;      // ZSTD_selectEncodingType's < lazy heuristic is the one seq_encode holds (U/ZstdCompressSequences.cs:400-469): levels whose strategy is lazy or above get greedy's constants
     size_t produced = 0;
@@ -303,10 +323,10 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, s);      c->timer.mark("lz_fast", s);
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, s);      c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s);        c->timer.mark("huf_build", s);
-        if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, s);             c->timer.mark("xxh64", s); }
-        launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, s);   c->timer.mark("seq_encode", s);
+        if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
@@ -947,6 +967,13 @@ size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); 
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 3) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* c, unsigned chunks) { if (!c || chunks == 0 || chunks > (1u << 20)) return ZERR(kErrParameterOutOfBound); c->passChunks = chunks; return 0; }
+// bytes: 0 = independent 64 KiB frames; > 0 = cross-chunk history of that many bytes per block (rounded to 4 KiB, at most 48 KiB);
+// < 0 = by level.  frameBytes: content of one multi-block frame (64 KiB .. 16 MiB), 0 = keep.
+size_t ZSTDMI_CCtx_setHistory(ZSTD_CCtx* c, int bytes, unsigned frameBytes)
+{
+    if (!c || bytes > (48 << 10) || (frameBytes && (frameBytes < kChunkSize || frameBytes > (16u << 20)))) return ZERR(kErrParameterOutOfBound);
+    c->historyBytes = bytes; if (frameBytes) c->frameBytes = frameBytes; return 0;
+}
 size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* c, int en) { if (!c) return ZERR(kErrGeneric); c->timer.enabled = en != 0; return 0; }
 size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* d, int en) { if (!d) return ZERR(kErrGeneric); d->timer.enabled = en != 0; return 0; }
 int ZSTDMI_CCtx_getStageTimes(const ZSTD_CCtx* c, float* ms, const char** names, int cap)
@@ -994,7 +1021,7 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, nullptr, 0, s);
     { const u32 plainReps[3] = { 1, 4, 8 };
       const Resolved rs = resolve_call(sticky_params(c), srcSize, kChunkSize);
-      launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy, 0, 0, 0, 0, plainReps, s); }
+      launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy, 0, 0, 0, 0, plainReps, 0, kChunkSize, 0, s); }
     if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
     if (m.blockType != 2) return 0;
