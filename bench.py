@@ -236,6 +236,8 @@ def main():
     ap.add_argument("--gather-method", default="p2p", choices=["p2p", "padded"], help="N>1: exact-size grouped send/recv, or one padded all-gather + compaction")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--history", type=int, default=None, help="cross-chunk history in KiB per block (0 = independent 64 KiB frames; default: by level, "
+                    "i.e. off at levels 1-2, 32 at levels >= 3)")
     args = ap.parse_args()
 
     import torch
@@ -274,13 +276,18 @@ def main():
         run_decompress(args, lib, z, torch, dist, dev, rank, world, local, make_input)
         return
     src, what = make_input(n, (1234 if args.input == "zipf" else 7) + rank)
-    workload = f"{args.size_mib} MiB {what} per GPU, level {args.level}, 64 KiB independent chunks"
+    hist_on = args.history > 0 if args.history is not None else args.level >= 3
+    framing = ("256 KiB frames of " + ("64 KiB blocks, far matches up to 188 KiB back" if args.level < 3 else "32 KiB blocks behind 32 KiB of history")) if hist_on \
+        else "one zstd frame per chunk"
+    workload = f"{args.size_mib} MiB {what} per GPU, level {args.level}, " + ("cross-chunk history" if hist_on else "64 KiB independent chunks")
     torch.cuda.synchronize()          # the library runs on its own stream: the input must be complete before the first call
     cap = lib.ZSTD_compressBound(n)
     dst = torch.empty(cap + 8192, dtype=torch.uint8, device=dev)      # slack: the gather pads a shard up to a multiple of 4096
     back = torch.empty(n, dtype=torch.uint8, device=dev)
     c, d = z.Compressor(args.level, device=local), z.Decompressor(device=local)
     lib.ZSTDMI_CCtx_setProfiling(c.cctx, 1); lib.ZSTDMI_DCtx_setProfiling(d.dctx, 1)
+    if args.history is not None:
+        assert lib.ZSTDMI_CCtx_setHistory(c.cctx, args.history << 10, 0) == 0
     comm = torch.cuda.Stream(device=dev) if world > 1 and not args.no_gather else None
     gathered = None
     # N > 1: the all-gather-v of step i runs on a side stream and overlaps the decompress of step i and the compress of step
@@ -365,7 +372,7 @@ def main():
             "metric": f"MB/s compress+decompress, level {args.level}", "value": round(world * n / (elapsed / K) / 1e6, 1) if ok else None, "unit": "MB/s",
             "n_gpus": world, "steps": K, "warmup": args.warmup, "ms_per_step": round(ms_step, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": workload, "chunk": 65536, "framing": "one zstd frame per chunk",
+            "config": {"workload": workload, "chunk": 65536, "framing": framing,
                        "gather": (f"all-gather-v of compressed shards over RCCL ({args.gather_method}) on a side stream, overlapped with the decompress of its step and the compress of the next" if comm is not None else "none"),
                        "parallelism": f"chunk-sharded x{world}"},
             "round_trip_bit_exact": ok, "ratio": round(ratio, 5),

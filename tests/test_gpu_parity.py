@@ -169,9 +169,11 @@ def _gpu_chunk(lib, cctx, idx):
     return _seqs_to_list(seqs, ns.value), lits.raw[:ls.value]
 
 
-def _replay(seqs, lits, n):
-    """Execute sequences the way the decoder does (repcode history included) -> reconstructed bytes."""
-    out = bytearray(); rep = [1, 4, 8]; lp = 0
+def _replay(seqs, lits, n, history=b"", rep=(1, 4, 8)):
+    """Execute sequences the way the decoder does (repcode history included) -> reconstructed bytes.  history: what the frame
+    holds in front of this block (a later block of a multi-block frame); rep: the repcodes the block may rely on (a later block
+    is encoded against unknown ones, so any value must do: (0, 0, 0) makes a reliance fail the offset check)."""
+    out = bytearray(history); rep = list(rep); lp = 0; n += len(history)
     for off_base, ll, mlb in seqs:
         out += lits[lp:lp + ll]; lp += ll
         ll0 = 1 if ll == 0 else 0
@@ -191,7 +193,7 @@ def _replay(seqs, lits, n):
             out.append(out[-off])
     out += lits[lp:]
     assert len(out) == n
-    return bytes(out)
+    return bytes(out[len(history):])
 
 
 @pytest.mark.parametrize("kind", ["text", "zipf", "runs", "mixed", "period", "zeros", "bytei"])
@@ -324,11 +326,28 @@ def test_level_finders_sequences_reconstruct_input(gpu_lib, level):
     with z.Compressor(level) as c:
         for kind in ("text", "mixed", "runs", "period"):
             data = datagen.gen(kind, 65536 + 30000, 3)
+            assert gpu_lib.ZSTDMI_CCtx_setHistory(c.cctx, 0, 0) == 0          # independent 64 KiB chunks
             c.Wrap(data)
             for idx, (lo, hi) in enumerate([(0, 65536), (65536, len(data))]):
                 seqs, lits = _gpu_chunk(gpu_lib, c.cctx, idx)
                 assert _replay(seqs, lits, hi - lo) == data[lo:hi]
                 assert all(mlb + 3 >= 4 for _, _, mlb in seqs)
+            # the level's default: blocks of 32 KiB that match into the 32 KiB in front of them (row f-1); a later block's
+            # sequences replay against the frame so far and never lean on repcodes they did not define themselves
+            assert gpu_lib.ZSTDMI_CCtx_setHistory(c.cctx, -1, 0) == 0
+            c.Wrap(data)
+            reach = 0
+            for idx, lo in enumerate(range(0, len(data), 32768)):
+                hi = min(lo + 32768, len(data))
+                seqs, lits = _gpu_chunk(gpu_lib, c.cctx, idx)
+                assert _replay(seqs, lits, hi - lo, history=data[:lo], rep=(1, 4, 8) if idx == 0 else (0, 0, 0)) == data[lo:hi]
+                pos = 0
+                for off_base, ll, mlb in seqs:
+                    pos += ll
+                    if off_base > 3: reach = max(reach, off_base - 3 - pos)
+                    pos += mlb + 3
+            assert reach <= 32768, "history is the 32 KiB in front of the block"
+            if kind in ("text", "period"): assert reach > 0, "some match must reach in front of its block"
 
 
 def test_levels_buy_ratio(gpu_lib, oracle):
@@ -498,13 +517,13 @@ def test_level5_compress_at_size(gpu_lib, oracle):
         cs1 = gpu_lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), unique)      # the first 64 MiB alone: same frames
         head = dst[:cs1].cpu().numpy().tobytes()
         cs = gpu_lib.ZSTDMI_compressDevice(c.cctx, dst.data_ptr(), cap, src.data_ptr(), n)
-        assert dst[:cs1].cpu().numpy().tobytes() == head, "chunks are independent: a prefix of the input gives a prefix of the output"
+        assert dst[:cs1].cpu().numpy().tobytes() == head, "frames are independent: a prefix of the input (whole frames) gives a prefix of the output"
         assert gpu_lib.ZSTDMI_decompressDevice(d.dctx, out.data_ptr(), n, dst.data_ptr(), cs) == n
         assert torch.equal(out, src)
         assert cs < 0.47 * n
     k = gpu_lib.ZSTD_findFrameCompressedSize(head, len(head))
     end = 0
-    for _ in range(64):                                              # the first 64 frames = 4 MiB
+    for _ in range(16):                                              # the first 16 frames = 4 MiB (level 5: 256 KiB frames of 32 KiB blocks)
         end += gpu_lib.ZSTD_findFrameCompressedSize(head[end:], len(head) - end)
     assert k > 0 and oracle.decompress(head[:end], 4 << 20) == data[:4 << 20]
 

@@ -48,6 +48,10 @@ constexpr u32 kTileLog  = 12;
 constexpr u32 kGroups   = kTilePos / 64; // 64-position groups per tile
 constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; capped matches are finished by wave 0
 constexpr u32 kInPad    = 64;
+// FAR mode (row f-1 for the fast strategy): the table also holds positions of the input IN FRONT of the block, up to kFarMax
+// bytes back inside the block's frame; table entries are (rel + 1) << 14 | tag14 with rel = kFarMax + block position
+constexpr u32 kFarMax   = (192u << 10) - 4096;
+constexpr u32 kFarStep  = 2;             // every 2nd position of the far history is inserted (the reference's own table is sparser)
 static_assert((1u << kTileLog) == kTilePos && kGroups == 64, "tile geometry");
 
 struct LzLds {
@@ -58,7 +62,7 @@ struct LzLds {
     //   dual  : firstL u32[4096] | firstS u32[4096] (as `first`, indexed by the hash's upper 12 bits)
     //           tableL u16[8192] | tableS u16[8192] (position+1 of the hash's first occurrence in the latest earlier tile that had it)
     u32 tabMem[2u << kHashLog];
-    u8  tileLen[kTilePos];               // match length at each position of the tile (0 = none, kLenCap = "at least")
+    u8  tileLen[kTilePos];               // match length at each position of the tile (0 = none, kLenCap = "at least"); FAR: offset bits 16-17 on top
     u16 tileOff[kTilePos];
     u16 jump[kTilePos];                  // pointer-doubling array; afterwards: full length of capped selected matches
     u64 matchMask[kGroups];              // bit = position holds a match
@@ -136,11 +140,32 @@ __device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w,
     return l >= 4 ? l : 0;
 }
 
+// the same against a candidate in front of the block: its bytes come from global memory (g = the candidate's address; it lies
+// at least one byte before position p of the source, so every read below stays inside the source while p + l + 8 <= n)
+__device__ __forceinline__ u32 match_len_far(const LzLds& L, u32 p, const u8* __restrict__ g, u64 w, u32 n)
+{
+    const u64 cw = readLE64(g);
+    if ((u32)cw != (u32)w) return 0;
+    u64 x = w ^ cw;
+    u32 l = x ? (ctz64(x) >> 3) : 8;
+    if (!x) {
+        while (l < kLenCap && p + l + 8 <= n) {
+            x = lds_load8(L.in, p + l) ^ readLE64(g + l);
+            if (x) { l += ctz64(x) >> 3; break; }
+            l += 8;
+        }
+    }
+    if (l > n - p) l = n - p;
+    if (l > kLenCap) l = kLenCap;
+    return l >= 4 ? l : 0;
+}
+
 // MODE 0 = fast strategy (one 6-byte hash; levels 1-2 and the negative levels); 1 = doubleFast strategy (8-byte + SHORT-byte
 // hashes, four candidates per position; levels 3-4: the place of U/ZstdDoubleFast.cs:51-247); 2 = greedy and above (the dual
 // candidates + one-step lazy deferral; levels >= 5: the place of U/ZstdLazy.cs:1743-2032).  The host maps strategy -> MODE.
 // DICT: a dictionary prefix is present (its bounds checks fold away otherwise)
-template <int MODE, int SHORT, bool DICT>
+// FAR: matches may start in the input in front of the block (same frame): those candidates are verified against global memory
+template <int MODE, int SHORT, bool DICT, bool FAR>
 __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u64 srcSize,
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
@@ -162,7 +187,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     const u32 hist = DICT ? kChunkSize - chunkBytes : 0u;
     const u64 base = (u64)c * cb;
     const u8* __restrict__ in = src + base;
-    const u32 bf = (DICT && frameBlocks) ? c % frameBlocks : 0u;                       // block index inside its frame
+    const u32 bf = ((DICT || FAR) && frameBlocks) ? c % frameBlocks : 0u;               // block index inside its frame
+    const u32 farAvail = FAR ? ((u64)bf * cb < kFarMax ? bf * cb : kFarMax) : 0u;      // bytes of far history in front of the block
     u32 prefixLen = prefixLenArg; const u8* __restrict__ prefix = prefixArg;
     if (DICT && frameBlocks) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
     const u32 lowLimit = DICT ? hist - prefixLen : 0u;
@@ -214,6 +240,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     }
     if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.nzWords[2] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; L.matchCount[2] = 0; }
     __syncthreads();
+    if (FAR && farAvail) {
+        // the table starts out holding the input in front of the block (what the reference's table still holds from the blocks
+        // before, U/ZstdFast.cs:9-46): latest occurrence per bucket, straight from global memory
+        for (u32 i = tid * kFarStep; i < farAvail; i += kTile * kFarStep) {
+            const u32 hp = hash6p(readLE64(in - farAvail + i));
+            atomicMax(&table[hidx(hp)], ((kFarMax - farAvail + i + 1) << 14) | (htag(hp) >> 2));
+        }
+        __syncthreads();
+    }
     ZMI_STAMP(0);
 
     Seq* __restrict__ seqOut = seqs + (u64)c * kMaxSeq;
@@ -231,14 +266,18 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u64* cov = L.covMask[0];             // coverage words of the current tile (64, or 256 for a super-tile)
     u32 span = kTilePos;                 // positions the current tile covers
     // ix = index into the tile arrays (the position, or the probe slot of a super-tile), q = tile-relative position
+    auto tile_len = [&](u32 ix) -> u32 { return FAR ? (u32)L.tileLen[ix] & 63u : (u32)L.tileLen[ix]; };
+    auto tile_off = [&](u32 ix) -> u32 { return FAR ? (u32)L.tileOff[ix] | (((u32)L.tileLen[ix] >> 6) << 16) : (u32)L.tileOff[ix]; };
     auto emit_match = [&](u32 tileStart, u32 ix, u32 q, u32 rank, u32 end) {
         u32 p = tileStart + q;
-        const u32 off = L.tileOff[ix];
+        const u32 off = tile_off(ix);
         const u32 litStart = endOf[rank];
         const u32 floorPos = litStart > tileStart ? litStart : tileStart;     // literals of earlier tiles are already emitted
         // backward: give bytes of the pending literal run to the match while they agree (ZstdFast.cs:242-247)
         // (four bytes per step: the dwords in front of the match and of its source, compared from the top)
-        for (;;) {
+        if (FAR && off > p) {                                          // the source lies in front of the block: byte steps against global memory
+            while (p > floorPos && off - p < farAvail && L.in[p - 1] == in[(s64)p - 1 - (s64)off]) --p;
+        } else for (;;) {
             u32 room = p - floorPos;                                   // bytes the pending literal run can give
             const u32 srcRoom = p - off - lowLimit;                    // bytes in front of the source
             if (srcRoom < room) room = srcRoom;
@@ -268,7 +307,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         u32 e = p + kLenCap;
         for (;;) {
             const u32 pos = e + 8 * lane;              // reads past n land in the table region: harmless, clamped below
-            const u64 x = lds_load8(L.in, pos) ^ lds_load8(L.in, pos - off);
+            const s32 sp = (s32)pos - (s32)off;                        // FAR: a negative source position is in front of the block
+            const u64 x = lds_load8(L.in, pos) ^ ((FAR && sp < 0) ? readLE64(in + sp) : lds_load8(L.in, (u32)sp));
             const u64 bad = ballot(x != 0 || pos + 8 > n);
             if (bad == 0) { e += 512; continue; }
             const u32 fl = ctz64(bad);
@@ -368,7 +408,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             const u32 q = probed(j), p = tileStart + q;
             u32 len = 0, off = 0;
             if (valid[j]) {
-                if (MODE == 0 && !fused) atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | htag(h[j]));
+                if (MODE == 0 && !fused) atomicMax(&table[hidx(h[j])], FAR ? ((kFarMax + p + 1) << 14) | (htag(h[j]) >> 2) : ((p + 1) << 16) | htag(h[j]));
                 // (1) periods 1..4: bytes p..p+7 repeat with period d and the d bytes before p agree — runs and tiny
                 //     patterns, which neither table can see inside one tile
                 u32 per = 0;
@@ -397,7 +437,14 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                             const u32 cpos = tileStart + fq;
                             len = match_len(L, p, cpos, w[j], n); off = p - cpos;
                         }
-                        if (cand[j] && (cand[j] & 0xFFFFu) == tag && len < kLenCap) {
+                        if (FAR) {
+                            if (cand[j] && (cand[j] & 0x3FFFu) == (tag >> 2) && len < kLenCap) {
+                                const u32 crel = (cand[j] >> 14) - 1;                 // kFarMax + position; below kFarMax: in front of the block
+                                const u32 l2 = crel >= kFarMax ? match_len(L, p, crel - kFarMax, w[j], n)
+                                                               : match_len_far(L, p, in - (kFarMax - crel), w[j], n);
+                                if (l2 > len) { len = l2; off = kFarMax + p - crel; }
+                            }
+                        } else if (cand[j] && (cand[j] & 0xFFFFu) == tag && len < kLenCap) {
                             const u32 cpos = (cand[j] >> 16) - 1;
                             const u32 l2 = match_len(L, p, cpos, w[j], n);
                             if (l2 > len) { len = l2; off = p - cpos; }
@@ -456,7 +503,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (g2 > g1) len = 0;
                 }
             }
-            if (len) { const u32 ix = arr_ix(j, q); L.tileLen[ix] = (u8)len; L.tileOff[ix] = (u16)off; }      // only read where matchMask has the bit
+            if (len) { const u32 ix = arr_ix(j, q); L.tileLen[ix] = (u8)(FAR ? len | ((off >> 16) << 6) : len); L.tileOff[ix] = (u16)off; }      // only read where matchMask has the bit
             mmJ[j] = ballot(len != 0); cmJ[j] = ballot(len == kLenCap);
             if (!slotMasks) {
                 if (len) {
@@ -516,7 +563,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 const u64 mm = (u64)uniform((u32)mmv) | ((u64)uniform((u32)(mmv >> 32)) << 32);
                 mmS[k] = mm;
                 const bool has = (mm >> lane) & 1ull;
-                const u32 len = has ? (u32)L.tileLen[g * 64 + lane] : 0u;
+                const u32 len = has ? tile_len(g * 64 + lane) : 0u;
                 const u32 t = lane + len;                                     // a match: its end; no match here: the cursor itself
                 u32 j = t;                                                    // >= 64: leaves the segment at offset t - 64 (< 32)
                 if (t < 64) { const u64 rest = mm >> t; j = rest ? t + ctz64(rest) : 64u; }
@@ -577,7 +624,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     const u32 g = ctz64(have);
                     const u32 q = g * 64 + ctz64(read_lane64(wm, g));
                     const u32 p = tileStart + q;
-                    const u32 e = finish_capped(p, L.tileOff[q]);
+                    const u32 e = finish_capped(p, tile_off(q));
                     if (lane == 0) L.jump[q] = (u16)(e - p > 0xFFFFu ? 0xFFFFu : e - p);
                     const u32 r0 = q + 1, r1 = (e - tileStart) < kTilePos ? (e - tileStart) : kTilePos;   // swallowed: [r0, r1)
                     if (r1 > r0) {
@@ -610,7 +657,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 const u64 sm = L.selMask[q >> 6];
                 if ((sm >> (q & 63)) & 1ull) {
                     const u32 rank = L.wordRank[q >> 6] + popc64(sm & ((1ull << (q & 63)) - 1));
-                    const u32 len = L.tileLen[q];
+                    const u32 len = tile_len(q);
                     endOf[rank + 1] = tileStart + q + (len == kLenCap ? (u32)L.jump[q] : len);
                     selPos[rank] = (u16)q;
                 }
@@ -643,7 +690,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     const bool have = lane < nB;
                     const u32 ix = have ? L.sparseList[lane] : 0;
                     const u32 q = super ? slot_pos(ix) : ix;
-                    const u32 len = have ? L.tileLen[ix] : 0, off = have ? L.tileOff[ix] : 0;
+                    const u32 len = have ? tile_len(ix) : 0, off = have ? tile_off(ix) : 0;
                     u32 myEnd = 0; u64 selBits = 0;
                     for (u32 i = 0; i < nB; ++i) {
                         const u32 qi = read_lane(q, i);
@@ -753,7 +800,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     if (tid == 0) {
         ChunkMeta m = {};
         m.srcSize = nData; m.nbSeq = nbSeq; m.litSize = litBase;
-        if (DICT && frameBlocks) {            // only a frame's first block carries the frame header, sized for the whole frame's content
+        if ((DICT || FAR) && frameBlocks) {   // only a frame's first block carries the frame header, sized for the whole frame's content
             const u64 fStart = base - (u64)bf * cb, fMax = (u64)frameBlocks * cb;
             const u64 fLen = (srcSize - fStart) < fMax ? (srcSize - fStart) : fMax;
             m.fhSize = bf == 0 ? frame_header_size64(fLen) + fhExtra : 0u;
@@ -773,7 +820,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 }
 #endif
 
-template <int MODE, int SHORT, bool DICT>
+template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                        u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream)
 {
@@ -781,10 +828,10 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
     static bool attrSet[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (!attrSet[dev & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -795,6 +842,10 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream)
 {
+    if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
+        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, stream);
+        return;
+    }
     if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
         switch (finder) {
         case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;

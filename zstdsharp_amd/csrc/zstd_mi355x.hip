@@ -301,11 +301,15 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         int hb = c->historyBytes;
         if (hb < 0) hb = (rs.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (32 << 10) : 0;
         if (hb > 0) {
-            const u32 histB = round_tile((size_t)hb) > (48u << 10) ? (48u << 10) : round_tile((size_t)hb);
-            chunkBytes = kChunkSize - histB;
+            // what the level resolves to at the frame's size decides the form: the fast strategy keeps full 64 KiB blocks and
+            // finds far matches through its table (candidates in front of the block are verified against global memory, up to
+            // 188 KiB back); the dual-hash finders' 16-bit tables cannot hold far positions, so their blocks shrink to
+            // 64 KiB - hist and carry the hist bytes in front of them in LDS
+            const Resolved rf = resolve_call(cp, srcSize < c->frameBytes ? srcSize : c->frameBytes, c->frameBytes);
+            if (rf.finder == 0) chunkBytes = kChunkSize;
+            else { const u32 histB = round_tile((size_t)hb) > (48u << 10) ? (48u << 10) : round_tile((size_t)hb); chunkBytes = kChunkSize - histB; }
             frameBlocks = c->frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
-            const u64 frameLen = (u64)frameBlocks * chunkBytes;
-            rs = resolve_call(cp, srcSize < frameLen ? srcSize : frameLen, (u32)frameLen);
+            rs = rf;
         }
     }
     const u8* prefix = prefixLen ? (const u8*)c->dict.p + (c->dictHost.size() - prefixLen) : nullptr;
