@@ -28,47 +28,114 @@ extern "C" void ZSTDMI_debugReadSeqStamps(unsigned long long* out16, int reset)
 #define ZMI_SSTAMP(i) do { } while (0)
 #endif
 
-// sequences kernel: 10.4 KiB per wave
+// ---- seq_decode: kPack blocks per workgroup of four waves ----
+// The FSE state chain of a block (ZSTD_decodeSequence's three state updates, U/ZstdDecompressBlock.cs:2360-2484) is serial and
+// does the same few operations per sequence whatever runs it: on one wave per block every instruction moves ONE sequence
+// forward, and the kernel is bound by instruction issue (45 per sequence).  So a workgroup takes kPack consecutive blocks:
+//   A  their tables are built by the four waves, one (block, table) pair per wave at a time, 64 lanes each;
+//   B  wave 0 walks the chains, lane s = block s — kPack sequences per instruction, each lane with its own table slot in
+//      LDS and its own bit window — and leaves one (states, bit position) record per sequence, 64 sequences per block at a time;
+//   C  waves 1-3 turn the records of the PREVIOUS 64 sequences of each block into SeqRecs meanwhile (fields, repcodes, prefix
+//      sums: 64 lanes per block), two blocks per wave; one barrier per 64 sequences hands the record buffers over.
+constexpr u32 kPack = 6;                 // 6 x 5 KiB of tables + records: four workgroups per CU
+constexpr u32 kTabLL = 0, kTabML = 512, kTabOF = 1024, kTabWords = 1280;
+
 struct SeqLds {
-    SeqSym ll[512], ml[512], of[256];
-    s16 norm[64];
-    u16 symbolNext[64];
-    u32 llLog, mlLog, ofLog;
+    u32 tab[kPack][kTabWords];           // one entry per state: nextState:16 | nbBits:4 (bit 16) | nbAddBits:5 (bit 20) | symbol:6 (bit 25)
+    u32 recSt[2][kPack][64];             // phase B -> C (double-buffered): the three states before each of a block's 64 sequences ...
+    s32 recPos[2][kPack][64];            // ... and the bit position
+    s16 norm[4][64];                     // table-build scratch, one per wave
+    u16 symbolNext[4][64];
+    u32 logs[kPack];                     // llLog | ofLog << 8 | mlLog << 16, or 0xFFFFFFFF: some table of the block is corrupt
+    u32 tblErr[kPack][3];
+    u32 chainErr[kPack];
+    s32 endPos[kPack];
 };
+__device__ __forceinline__ u64 read_lane64(u64 v, u32 l) { return (u64)read_lane((u32)v, l) | ((u64)read_lane((u32)(v >> 32), l) << 32); }
+
+__device__ __forceinline__ u32 pack_entry(u32 sym, u32 nextState, u32 tableLog, u32 tableSize, int kind)
+{
+    const u32 nb = tableLog - highbit32(nextState);
+    const u32 add = kind == 0 ? (u32)dLL_bits[sym] : kind == 1 ? sym : (u32)dML_bits[sym];
+    return (((nextState << nb) - tableSize) & 0xFFFFu) | (nb << 16) | (add << 20) | (sym << 25);
+}
+
+// ZSTD_buildFSETable_body (U/ZstdDecompressBlock.cs:1571-1710) by the whole wave, as build_seq_dtable_wave (zmi_decode.h) but
+// into packed entries; until the last pass a cell holds its symbol.
+__device__ __forceinline__ void build_seq_ptable_wave(u32* t, u16* cum, const s16* norm, u32 maxSV, u32 tableLog, int kind, u32 lane)
+{
+    const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
+    const int nrm = lane <= maxSV ? (int)norm[lane] : 0;
+    const bool low = nrm == -1;
+    const u64 lowMask = ballot(low);
+    const u32 highThreshold = tableSize - 1 - popc64(lowMask);
+    if (low) t[tableSize - 1 - popc64(lowMask & lanemask_lt())] = lane;
+    const u32 cnt = nrm > 0 ? (u32)nrm : 0;
+    const u32 incl = wave_scan_incl(cnt);
+    cum[lane] = (u16)(incl - cnt);
+    wave_lds_sync();
+    u32 jBase = 0;
+    for (u32 i0 = 0; i0 < tableSize; i0 += 64) {
+        const u32 i = i0 + lane, p = (i * step) & mask;
+        const bool place = i < tableSize && p <= highThreshold;
+        const u64 bal = ballot(place);
+        const u32 j = jBase + popc64(bal & lanemask_lt());
+        jBase += popc64(bal);
+        if (place) {
+            u32 lo = 0, hi = 63;                 // largest symbol whose cumulative count is <= j
+#pragma unroll
+            for (u32 it = 0; it < 6; ++it) { const u32 mid = (lo + hi + 1) >> 1; if (cum[mid] <= j) lo = mid; else hi = mid - 1; }
+            t[p] = lo;
+        }
+    }
+    wave_lds_sync();
+    u32 nxt = low ? 1u : cnt;                    // symbolNext of symbol `lane`
+    for (u32 u0 = 0; u0 < tableSize; u0 += 64) {
+        const u32 u = u0 + lane; const bool valid = u < tableSize;
+        const u32 sym = valid ? t[u] : 0xFFFFu;
+        u32 myNext = 0;
+        u64 rem = ballot(valid);
+        while (rem) {
+            const u32 s0 = read_lane(sym, ctz64(rem));
+            const u64 m = ballot(sym == s0);
+            const u32 baseN = read_lane(nxt, s0);
+            if (sym == s0) myNext = baseN + popc64(m & lanemask_lt());
+            nxt = lane == s0 ? nxt + popc64(m) : nxt;
+            rem &= ~m;
+        }
+        wave_lds_sync();
+        if (valid) t[u] = pack_entry(sym, myNext, tableLog, tableSize, kind);
+    }
+    wave_lds_sync();
+}
 
 // One table of ZSTD_buildSeqTable (U/ZstdDecompressBlock.cs:1746-1840), whole wave; only the NCount header is parsed by one lane.
-// type: 0 predefined, 1 RLE, 2 compressed (repeat mode was resolved to the block that defined the table).  false = corrupt.
-__device__ __forceinline__ bool set_seq_table(SeqLds& L, SeqSym* t, u32* logPtr, u32 type, u32 max, u32 maxLog,
-                                              const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax, u32 lane)
+// type: 0 predefined, 1 RLE, 2 compressed (repeat mode was resolved to the block that defined the table).  Returns the table's
+// log, or 0xFFFFFFFF when the description is corrupt.
+__device__ __forceinline__ u32 set_seq_table(s16* norm, u16* symbolNext, u32* t, u32 type, u32 max, u32 maxLog,
+                                             const u8* src, u32 srcSize, int kind, const s16* defNorm, u32 defLog, u32 defMax, u32 lane)
 {
     switch (type) {
     case 1: {
-        if (!srcSize) return false;
+        if (!srcSize) return 0xFFFFFFFFu;
         const u32 sym = uniform((u32)src[0]);
-        if (sym > max) return false;
-        if (lane == 0) {
-            SeqSym e = seq_entry(sym, 1, 0, 1, kind); e.nextState = 0; e.nbBits = 0;
-            t[0] = e; *logPtr = 0;
-        }
+        if (sym > max) return 0xFFFFFFFFu;
+        if (lane == 0) t[0] = pack_entry(sym, 1, 0, 1, kind) & ~0x000FFFFFu;      // one state: no bits, stays where it is
         wave_lds_sync();
-        return true; }
+        return 0; }
     case 0:
-        if (lane <= defMax) L.norm[lane] = defNorm[lane];
+        if (lane <= defMax) norm[lane] = defNorm[lane];
         wave_lds_sync();
-        build_seq_dtable_wave(t, L.symbolNext, L.norm, defMax, defLog, kind, lane);
-        if (lane == 0) *logPtr = defLog;
-        wave_lds_sync();
-        return true;
+        build_seq_ptable_wave(t, symbolNext, norm, defMax, defLog, kind, lane);
+        return defLog;
     default: {
         u32 maxSV = max, tableLog = 0, hs = 0;
-        if (lane == 0) hs = read_ncount(L.norm, &maxSV, &tableLog, src, srcSize);
+        if (lane == 0) hs = read_ncount(norm, &maxSV, &tableLog, src, srcSize);
         hs = uniform(hs); maxSV = uniform(maxSV); tableLog = uniform(tableLog);
-        if (!hs || tableLog > maxLog) return false;
+        if (!hs || tableLog > maxLog) return 0xFFFFFFFFu;
         wave_lds_sync();
-        build_seq_dtable_wave(t, L.symbolNext, L.norm, maxSV, tableLog, kind, lane);
-        if (lane == 0) *logPtr = tableLog;
-        wave_lds_sync();
-        return true; }
+        build_seq_ptable_wave(t, symbolNext, norm, maxSV, tableLog, kind, lane);
+        return tableLog; }
     }
 }
 
@@ -80,140 +147,230 @@ __device__ __forceinline__ RepSlot rep_minus_one(RepSlot s)       // offset = re
     s.val += 1; return s;
 }
 
-__global__ __launch_bounds__(64) void seq_decode_kernel(const u8* __restrict__ src, const FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks,
-                                                        u32 nBlocks, SeqRec* __restrict__ recs, u32* __restrict__ status,
-                                                        const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
+// dword d (stream-relative, may lie outside) of a backward bitstream of `size` bytes at s; zeros outside the stream
+__device__ __forceinline__ u32 stream_dword_z(const u8* s, s32 size, s32 d)
+{
+    const s32 b = 4 * d;
+    if (b >= 0 && b + 4 <= size) return readLE32(s + b);
+    u32 v = 0;
+    for (s32 i = 0; i < 4; i++) { const s32 k = b + i; if (k >= 0 && k < size) v |= (u32)s[k] << (8 * i); }
+    return v;
+}
+// bits [p - nb, p) of the stream (nb <= 32), lane-private
+__device__ __forceinline__ u32 stream_field(const u8* s, s32 size, s32 p, u32 nb)
+{
+    if (!nb) return 0;
+    const s32 q = p - (s32)nb, by = q >> 3;
+    u64 v;
+    if (by >= 0 && by + 8 <= size) v = readLE64(s + by);
+    else { v = 0; for (s32 i = 0; i < 8; i++) { const s32 k = by + i; if (k >= 0 && k < size) v |= (u64)s[k] << (8 * i); } }
+    return (u32)(v >> (u32)(q & 7)) & (0xFFFFFFFFu >> (32 - nb));
+}
+
+// phase C for one block: records `buf` of its sequences [base, base + 64) -> SeqRecs; the block's running state (symbolic repcodes,
+// output and literal totals, error) is wave-uniform and lives in the caller's registers
+struct SlotState { RepSlot s0, s1, s2; u32 outBase, litUsed, err; };
+__device__ __forceinline__ void seq_fields_batch(const SeqLds& L, u32 buf, u32 sl, u32 base, u32 nbSeq, const u8* sp, s32 size, u32 litSize,
+                                                 SeqRec* __restrict__ rec, SlotState& S, u32 lane)
+{
+    const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
+    const u32* const T = L.tab[sl];
+    // ---- every lane: the fields of its own sequence ----
+    const bool have = lane < cnt;
+    u32 ll = 0, ml = 0, off = 1, code = 4;      // code 4 = a real offset; 0..3 = repcode selector
+    if (have) {
+        const u32 st = L.recSt[buf][sl][lane];
+        const u32 qLL = T[kTabLL + (st & 1023u)], qML = T[kTabML + ((st >> 10) & 1023u)], qOF = T[kTabOF + (st >> 20)];
+        const u32 aLL = (qLL >> 20) & 31u, aML = (qML >> 20) & 31u, aOF = (qOF >> 20) & 31u;
+        const u32 bLL = dLL_base[qLL >> 25], bML = dML_base[qML >> 25], bOF = of_base(qOF >> 25);
+        s32 p = L.recPos[buf][sl][lane];
+        const u32 ofv = stream_field(sp, size, p, aOF); p -= (s32)aOF;
+        const u32 mlv = stream_field(sp, size, p, aML); p -= (s32)aML;
+        const u32 llv = stream_field(sp, size, p, aLL);
+        ll = bLL + llv; ml = bML + mlv;
+        if (aOF > 1) off = bOF + ofv;
+        else code = bOF + (bLL == 0) + ofv;     // ofv is 0 or the single extra bit
+    }
+    // ---- repcodes, in sequence order (wave-uniform), relative to the block's starting ones ----
+    u32 tag = 0;
+    RepSlot s0 = S.s0, s1 = S.s1, s2 = S.s2;
+    {
+        const u64 repMask = ballot(have && code != 4);
+        if (!repMask && cnt >= 3) {
+            s0.kind = 0; s0.val = read_lane(off, cnt - 1); s1.kind = 0; s1.val = read_lane(off, cnt - 2); s2.kind = 0; s2.val = read_lane(off, cnt - 3);
+        } else {
+            for (u32 k = 0; k < cnt; k++) {
+                const u32 cd = read_lane(code, k);
+                if (cd == 4) { const u32 o = read_lane(off, k); s2 = s1; s1 = s0; s0.kind = 0; s0.val = o; }
+                else {
+                    RepSlot t;
+                    if (cd == 0) t = s0;
+                    else {
+                        t = cd == 1 ? s1 : (cd == 2 ? s2 : rep_minus_one(s0));
+                        if (cd != 1) s2 = s1;
+                        s1 = s0; s0 = t;
+                    }
+                    if (lane == k) { off = t.val; tag = t.kind; }
+                }
+            }
+        }
+    }
+    const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
+    const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
+    if (totalLit > litSize - S.litUsed) { S.err = kErrCorruption; return; }
+    if (totalOut > 0xFFFFFFFFu - S.outBase - litSize) { S.err = kErrCorruption; return; }     // (no valid block regenerates 4 GiB)
+    if (have) {
+        SeqRec r; r.off = off; r.llTag = ll | (tag << 30); r.ml = ml; r.pos = S.outBase + inclOut - ll - ml;
+        rec[base + lane] = r;
+    }
+    S.s0 = s0; S.s1 = s1; S.s2 = s2; S.outBase += totalOut; S.litUsed += totalLit;
+}
+
+__global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ src, const FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks,
+                                                         u32 nBlocks, SeqRec* __restrict__ recs, u32* __restrict__ status,
+                                                         const u8* __restrict__ dictFull, const DictInfo* __restrict__ di)
 {
     __shared__ SeqLds L;
-    const u32 bi = blockIdx.x, lane = threadIdx.x;
-    if (bi >= nBlocks) return;
-    BlockDesc& B = blocks[bi];
-    if (B.type != 2 || B.nbSeq == 0 || B.err) return;
+    const u32 lane = lane_id(), wave = uniform(wave_id()), b0 = blockIdx.x * kPack;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
-    const u32 nbSeq = uniform(B.nbSeq), bsz = uniform(B.bsz), litSize = uniform(B.litSize);
-    const u8* const b = src + B.srcOff;
-    u32 err = 0;
-    do {
-        // ---- the three tables, each from the block that defined it (ZSTD_decodeSeqHeaders, :1845-1943) ----
-        bool ok = true;
-#pragma unroll
-        for (u32 t = 0; t < 3 && ok; ++t) {                         // LL, OF, ML
-            const u32 s = uniform(B.tblSrc[t]);
-            const u8* d; u32 avail, mode;
-            if (s == kDictBlock) {                                  // dctx->fseEntropy from the dictionary (U/ZstdDecompress.cs:1956-1990)
-                const u32 o0 = uniform(t == 0 ? di->llOff : t == 1 ? di->ofOff : di->mlOff), o1 = uniform(t == 0 ? di->repOff : t == 1 ? di->mlOff : di->llOff);
-                d = dictFull + o0; avail = o1 - o0; mode = 2;
-            } else {
-                const BlockDesc& S = blocks[s];
-                mode = (uniform(S.modes) >> (6 - 2 * t)) & 3;
-                const u32 o = uniform(S.tblOff[t]);
-                d = src + S.srcOff + o; avail = uniform(S.bsz) - o;
-            }
-            if (t == 0)      ok = set_seq_table(L, L.ll, &L.llLog, mode, 35, 9, d, avail, 0, dLL_defaultNorm, 6, 35, lane);
-            else if (t == 1) ok = set_seq_table(L, L.of, &L.ofLog, mode, 31, 8, d, avail, 1, dOF_defaultNorm, 5, 28, lane);
-            else             ok = set_seq_table(L, L.ml, &L.mlLog, mode, 52, 9, d, avail, 2, dML_defaultNorm, 6, 52, lane);
-            if (!ok) err = s == kDictBlock ? (u32)kErrDictionaryCorrupted : (u32)kErrCorruption;
-        }
-        if (err) break;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-        // ---- sequences (ZSTD_decompressSequences_body, :2668-2763), 64 at a time ----
-        // The state chain (ZSTD_decodeSequence's three FSE updates, :2360-2484) only needs the LENGTHS of the extra-bit fields, so it
-        // runs wave-uniform on the scalar unit and records, per sequence, the three states and the bit position; each lane then
-        // reads the fields of its own sequence.
-        const u32 bitsOff = uniform(B.bitsOff);
-        SBits bd;
-        if (bitsOff >= bsz || !bd.init(b + bitsOff, (s32)(bsz - bitsOff), lane)) { err = kErrCorruption; break; }
-        u32 sLL = bd.read(L.llLog, lane), sOF = bd.read(L.ofLog, lane), sML = bd.read(L.mlLog, lane);
-        RepSlot s0 = { 1, 0 }, s1 = { 2, 0 }, s2 = { 3, 0 };       // the block's starting repcodes, symbolically
-        u32 outBase = 0, litUsed = 0;
-        SeqRec* __restrict__ const rec = recs + B.seqBase;
-        for (u32 base = 0; base < nbSeq; base += 64) {
-            const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
-            u32 recSt = 0; s32 recPos = 0;
-            ZMI_SSTAMP(0);
-            for (u32 k = 0; k < cnt; k++) {
-                // SeqSym = nextState:16 | nbAddBits:8 | nbBits:8 | baseValue:32 ; only the first dword matters here
-                const u32 vLL = *reinterpret_cast<const u32*>(&L.ll[sLL]), vML = *reinterpret_cast<const u32*>(&L.ml[sML]),
-                          vOF = *reinterpret_cast<const u32*>(&L.of[sOF]);
-                const u32 pk = sLL | (sML << 10) | (sOF << 20);
-                recSt = lane == k ? pk : recSt; recPos = lane == k ? bd.pos : recPos;
-                const u32 eLL = uniform(vLL), eML = uniform(vML), eOF = uniform(vOF);
-                const u32 nLL = eLL >> 24, nML = eML >> 24, nOF = eOF >> 24;
-                bd.pos -= (s32)(((eLL >> 16) & 0xFF) + ((eML >> 16) & 0xFF) + ((eOF >> 16) & 0xFF));   // the extra-bit fields
-                // the three state updates read LL, ML, OF bits in that order: one extraction, split afterwards
-                const u32 all = bd.read(nLL + nML + nOF, lane);
-                sLL = (vLL & 0xFFFF) + (all >> (nML + nOF));
-                sML = (vML & 0xFFFF) + ((all >> nOF) & ~(0xFFFFFFFFu << nML));
-                sOF = (vOF & 0xFFFF) + (all & ~(0xFFFFFFFFu << nOF));
-            }
-            ZMI_SSTAMP(1);
-            // ---- every lane: the fields of its own sequence ----
-            const bool have = lane < cnt;
-            u32 ll = 0, ml = 0, off = 1, code = 4;      // code 4 = a real offset; 0..3 = repcode selector
-            if (have) {
-                const SeqSym qLL = L.ll[recSt & 1023], qML = L.ml[(recSt >> 10) & 1023], qOF = L.of[recSt >> 20];
-                s32 p = recPos;
-                const u32 ofv = bd.field(p, qOF.nbAddBits); p -= qOF.nbAddBits;
-                const u32 mlv = bd.field(p, qML.nbAddBits); p -= qML.nbAddBits;
-                const u32 llv = bd.field(p, qLL.nbAddBits);
-                ll = qLL.baseValue + llv; ml = qML.baseValue + mlv;
-                if (qOF.nbAddBits > 1) off = qOF.baseValue + ofv;
-                else code = qOF.baseValue + (qLL.baseValue == 0) + ofv;     // ofv is 0 or the single extra bit
-            }
-            // ---- repcodes, in sequence order (wave-uniform), relative to the block's starting ones ----
-            u32 tag = 0;
-            {
-                const u64 repMask = ballot(have && code != 4);
-                if (!repMask && cnt >= 3) {
-                    s0.kind = 0; s0.val = read_lane(off, cnt - 1); s1.kind = 0; s1.val = read_lane(off, cnt - 2); s2.kind = 0; s2.val = read_lane(off, cnt - 3);
+    // ---- phase A: the tables, each from the block that defined it (ZSTD_decodeSeqHeaders, :1845-1943); task = (slot, table) ----
+    for (u32 task = wave; task < kPack * 3; task += 4) {
+        const u32 sl = task / 3, t = task % 3;                      // t: 0 LL, 1 OF, 2 ML
+        const u32 bi = b0 + sl;
+        u32 res = 0;                                                // tableLog, or an error code << 8 | 0xFF
+        if (bi < nBlocks) {
+            const BlockDesc& B = blocks[bi];
+            if (uniform((u32)B.type) == 2 && uniform(B.nbSeq) != 0 && !uniform(B.err)) {
+                const u32 s = uniform(B.tblSrc[t]);
+                const u8* d; u32 avail, mode;
+                if (s == kDictBlock) {                              // dctx->fseEntropy from the dictionary (U/ZstdDecompress.cs:1956-1990)
+                    const u32 o0 = uniform(t == 0 ? di->llOff : t == 1 ? di->ofOff : di->mlOff), o1 = uniform(t == 0 ? di->repOff : t == 1 ? di->mlOff : di->llOff);
+                    d = dictFull + o0; avail = o1 - o0; mode = 2;
                 } else {
-                    for (u32 k = 0; k < cnt; k++) {
-                        const u32 cd = read_lane(code, k);
-                        if (cd == 4) { const u32 o = read_lane(off, k); s2 = s1; s1 = s0; s0.kind = 0; s0.val = o; }
-                        else {
-                            RepSlot t;
-                            if (cd == 0) t = s0;
-                            else {
-                                t = cd == 1 ? s1 : (cd == 2 ? s2 : rep_minus_one(s0));
-                                if (cd != 1) s2 = s1;
-                                s1 = s0; s0 = t;
-                            }
-                            if (lane == k) { off = t.val; tag = t.kind; }
-                        }
-                    }
+                    const BlockDesc& S = blocks[s];
+                    mode = (uniform(S.modes) >> (6 - 2 * t)) & 3;
+                    const u32 o = uniform(S.tblOff[t]);
+                    d = src + S.srcOff + o; avail = uniform(S.bsz) - o;
+                }
+                u32 lg;
+                if (t == 0)      lg = set_seq_table(L.norm[wave], L.symbolNext[wave], L.tab[sl] + kTabLL, mode, 35, 9, d, avail, 0, dLL_defaultNorm, 6, 35, lane);
+                else if (t == 1) lg = set_seq_table(L.norm[wave], L.symbolNext[wave], L.tab[sl] + kTabOF, mode, 31, 8, d, avail, 1, dOF_defaultNorm, 5, 28, lane);
+                else             lg = set_seq_table(L.norm[wave], L.symbolNext[wave], L.tab[sl] + kTabML, mode, 52, 9, d, avail, 2, dML_defaultNorm, 6, 52, lane);
+                res = lg == 0xFFFFFFFFu ? ((s == kDictBlock ? (u32)kErrDictionaryCorrupted : (u32)kErrCorruption) << 8) | 0xFFu : lg;
+            }
+        }
+        if (lane == 0) L.tblErr[sl][t] = res;
+    }
+    __syncthreads();
+    ZMI_SSTAMP(0);
+    // ---- what every wave needs of the blocks (lane s < kPack = slot s) ----
+    const u32 myBi = (lane < kPack && b0 + lane < nBlocks) ? b0 + lane : b0;
+    BlockDesc& MB = blocks[myBi];
+    u32 mNbSeq = 0, mErr = 0, myLogs = 0;
+    if (lane < kPack && b0 + lane < nBlocks && MB.type == 2 && MB.nbSeq != 0 && !MB.err) {
+        const u32 r0 = L.tblErr[lane][0], r1 = L.tblErr[lane][1], r2 = L.tblErr[lane][2];
+        // the reference stops at the first corrupt table in LL, OF, ML order
+        if ((r0 & 0xFF) == 0xFF) mErr = r0 >> 8; else if ((r1 & 0xFF) == 0xFF) mErr = r1 >> 8; else if ((r2 & 0xFF) == 0xFF) mErr = r2 >> 8;
+        else { mNbSeq = MB.nbSeq; myLogs = r0 | (r1 << 8) | (r2 << 16); }
+    }
+    const u32 mBsz = MB.bsz, mBitsOff = MB.bitsOff, mLitSize = MB.litSize;
+    const u8* const mSp = src + MB.srcOff + mBitsOff;
+    const s32 mSize = (s32)(mBsz - mBitsOff);
+    const u64 mSeqBase = MB.seqBase;
+    s32 pos = 0; u32 sLL = 0, sML = 0, sOF = 0;
+    if (mNbSeq) {
+        const u32 last = (mBitsOff < mBsz) ? (u32)mSp[mSize - 1] : 0u;
+        if (mBitsOff >= mBsz || !last) { mErr = kErrCorruption; mNbSeq = 0; }
+        else {
+            pos = (mSize - 1) * 8 + (s32)highbit32(last);
+            const u32 llLog = myLogs & 0xFF, ofLog = (myLogs >> 8) & 0xFF, mlLog = (myLogs >> 16) & 0xFF;
+            sLL = stream_field(mSp, mSize, pos, llLog); pos -= (s32)llLog;
+            sOF = stream_field(mSp, mSize, pos, ofLog); pos -= (s32)ofLog;
+            sML = stream_field(mSp, mSize, pos, mlLog); pos -= (s32)mlLog;
+        }
+    }
+    const u32 maxSeq = wave_max(mNbSeq);                            // (the same in every wave)
+    const u32 nBatch = (maxSeq + 63) >> 6;
+    // phase C: wave w (1..3) owns slots w - 1 and w + 2
+    const u32 slA = wave ? wave - 1 : 0, slB = wave ? wave + 2 : 0;
+    SlotState SA = { { 1, 0 }, { 2, 0 }, { 3, 0 }, 0, 0, 0 }, SB = SA;       // the block's starting repcodes, symbolically
+    const u32 nbA = read_lane(mNbSeq, slA), nbB = read_lane(mNbSeq, slB);
+    const u8* const spA = reinterpret_cast<const u8*>(read_lane64((u64)(uintptr_t)mSp, slA));
+    const u8* const spB = reinterpret_cast<const u8*>(read_lane64((u64)(uintptr_t)mSp, slB));
+    const s32 sizeA = (s32)read_lane((u32)mSize, slA), sizeB = (s32)read_lane((u32)mSize, slB);
+    const u32 litA = read_lane(mLitSize, slA), litB = read_lane(mLitSize, slB);
+    SeqRec* __restrict__ const recA = recs + read_lane64(mSeqBase, slA);
+    SeqRec* __restrict__ const recB = recs + read_lane64(mSeqBase, slB);
+    const u32* const mT = L.tab[lane < kPack ? lane : 0];
+    for (u32 bt = 0; bt <= nBatch; ++bt) {
+        const u32 base = bt << 6;
+        if (wave == 0) {
+            // ---- phase B: 64 steps of every chain.  Per sequence a lane reads its three table entries (LDS) and, independently of
+            // them, the 128 stream bits below its bit position (global memory; a stream is walked downward, so these loads stay in
+            // one cache line for a dozen sequences); the extra-bit fields are only skipped here ----
+            if (base < mNbSeq) {
+                const u32 steps = mNbSeq - base < 64 ? mNbSeq - base : 64, buf = bt & 1;
+                for (u32 k = 0; k < steps; ++k) {
+                    const u32 eLL = mT[kTabLL + sLL], eML = mT[kTabML + sML], eOF = mT[kTabOF + sOF];
+                    const s32 dl = ((pos - 1) >> 5) - 3;                // the window: stream dwords dl .. dl + 3, at least bits [pos - 97, pos)
+                    u32 w0, w1, w2, w3;
+                    if (dl >= 0 && 4 * dl + 16 <= mSize) {
+                        const u64 a = readLE64(mSp + 4 * dl), b = readLE64(mSp + 4 * dl + 8);
+                        w0 = (u32)a; w1 = (u32)(a >> 32); w2 = (u32)b; w3 = (u32)(b >> 32);
+                    } else { w0 = stream_dword_z(mSp, mSize, dl); w1 = stream_dword_z(mSp, mSize, dl + 1); w2 = stream_dword_z(mSp, mSize, dl + 2); w3 = stream_dword_z(mSp, mSize, dl + 3); }
+                    L.recSt[buf][lane][k] = sLL | (sML << 10) | (sOF << 20); L.recPos[buf][lane][k] = pos;
+                    const u32 nLL = (eLL >> 16) & 15u, nML = (eML >> 16) & 15u, nOF = (eOF >> 16) & 15u, nbTot = nLL + nML + nOF;
+                    const s32 q = pos - (s32)(((eLL >> 20) & 31u) + ((eML >> 20) & 31u) + ((eOF >> 20) & 31u)) - (s32)nbTot;
+                    const u32 rr = (u32)(q - 32 * dl), ix = rr >> 5;     // q >= pos - 89 >= 32 dl + 8
+                    const u32 lo = ix == 0 ? w0 : ix == 1 ? w1 : ix == 2 ? w2 : w3;
+                    const u32 hi = ix == 0 ? w1 : ix == 1 ? w2 : ix == 2 ? w3 : 0u;
+                    const u32 all = __builtin_amdgcn_alignbit(hi, lo, rr & 31u) & ~(0xFFFFFFFFu << nbTot);
+                    sLL = (eLL & 0xFFFFu) + (all >> (nML + nOF));
+                    sML = (eML & 0xFFFFu) + ((all >> nOF) & ~(0xFFFFFFFFu << nML));
+                    sOF = (eOF & 0xFFFFu) + (all & ~(0xFFFFFFFFu << nOF));
+                    pos = q;
                 }
             }
-            ZMI_SSTAMP(2);
-            const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
-            const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
-            if (totalLit > litSize - litUsed) { err = kErrCorruption; break; }
-            if (totalOut > 0xFFFFFFFFu - outBase - litSize) { err = kErrCorruption; break; }     // (no valid block regenerates 4 GiB)
-            if (have) {
-                SeqRec r; r.off = off; r.llTag = ll | (tag << 30); r.ml = ml; r.pos = outBase + inclOut - ll - ml;
-                rec[base + lane] = r;
-            }
-            outBase += totalOut; litUsed += totalLit;
-            ZMI_SSTAMP(3);
+        } else if (bt) {
+            // ---- phase C for the previous 64 sequences of this wave's two blocks ----
+            const u32 pbase = base - 64, buf = (bt - 1) & 1;
+            if (pbase < nbA && !SA.err) seq_fields_batch(L, buf, slA, pbase, nbA, spA, sizeA, litA, recA, SA, lane);
+            if (pbase < nbB && !SB.err) seq_fields_batch(L, buf, slB, pbase, nbB, spB, sizeB, litB, recB, SB, lane);
         }
-        if (err) break;
-        if (bd.pos > 0) { err = kErrCorruption; break; }          // bitstream not fully consumed (:2730-2733)
-        if (lane == 0) {
-            B.outSize = outBase + (litSize - litUsed);
-            B.repKind[0] = s0.kind; B.repVal[0] = s0.val; B.repKind[1] = s1.kind; B.repVal[1] = s1.val; B.repKind[2] = s2.kind; B.repVal[2] = s2.val;
+        __syncthreads();
+    }
+    ZMI_SSTAMP(1);
+    // ---- results ----
+    if (wave == 0 && lane < kPack) { L.chainErr[lane] = mErr; L.endPos[lane] = pos; }
+    __syncthreads();
+    if (wave && lane == 0) {
+#pragma unroll
+        for (u32 h = 0; h < 2; ++h) {
+            const u32 sl = h ? slB : slA; const SlotState& S = h ? SB : SA;
+            const u32 bi = b0 + sl;
+            if (bi >= nBlocks) continue;
+            BlockDesc& B = blocks[bi];
+            if (B.type != 2 || B.nbSeq == 0 || B.err) continue;
+            u32 err = L.chainErr[sl];                               // tables, end mark
+            if (!err) err = S.err;
+            if (!err && L.endPos[sl] > 0) err = kErrCorruption;     // bitstream not fully consumed (:2730-2733)
+            if (err) { B.err = err; report_error(status, bi, kStageSequences, err); continue; }
+            B.outSize = S.outBase + (B.litSize - S.litUsed);
+            B.repKind[0] = S.s0.kind; B.repVal[0] = S.s0.val; B.repKind[1] = S.s1.kind; B.repVal[1] = S.s1.val; B.repKind[2] = S.s2.kind; B.repVal[2] = S.s2.val;
         }
-    } while (false);
-    if (err && lane == 0) { B.err = err; report_error(status, bi, kStageSequences, err); }
+    }
+    ZMI_SSTAMP(2);
 #ifdef ZMI_LZ_STAMPS
-    if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_seqStamps[i], stampAcc[i]);
+    if (wave == 0 && lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_seqStamps[i], stampAcc[i]);
 #endif
 }
 
 void launch_seq_decode(const u8* src, const FrameDesc* frames, BlockDesc* blocks, u32 nBlocks, SeqRec* recs, u32* status,
                        const u8* dictFull, const DictInfo* di, hipStream_t stream)
 {
-    hipLaunchKernelGGL(seq_decode_kernel, dim3(nBlocks), dim3(64), 0, stream, src, frames, blocks, nBlocks, recs, status, dictFull, di);
+    hipLaunchKernelGGL(seq_decode_kernel, dim3((nBlocks + kPack - 1) / kPack), dim3(256), 0, stream, src, frames, blocks, nBlocks, recs, status, dictFull, di);
 }
 
 // ------------------------------------------------------------------------------------------------
