@@ -47,6 +47,7 @@ struct SeqWaveLds {
     s16 norm[64]; u16 cumul[66]; u8 tableSymbol[512];
     // one batch of 64 sequences: codes in, (state bits, count) out of the three chains, and the packing tile
     u8  bCode[3][64];
+    SymTT bTT[3][64];                   // the symbol transforms of the batch's codes, looked up by the 64 lanes (the chains only add and shift)
     u32 bBits[3][64];                   // low 16: value, high 16: number of bits
     u32 tile[192];
 };
@@ -165,11 +166,14 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
                                                          const u32 frameBlocks, const u32 chunkBytes, const u64 srcSize)
 {
     __shared__ SeqWaveLds Ws[4];
-    const u32 lane = lane_id(), wave = wave_id();
+    __shared__ u32 sBatchSeq[4];          // sequences each of the four chunks sends through the state chains (0: none)
+    __shared__ u32 sFinalState[4][3];
+    const u32 lane = lane_id(), wave = uniform(wave_id());
     const u32 c = blockIdx.x * 4 + wave;
-    if (c >= nChunks) return;
+    const bool live = c < nChunks;        // (a wave without a chunk still meets the workgroup's barriers below)
     SeqWaveLds& W = Ws[wave];
-    ChunkMeta m = meta[c];
+    ChunkMeta m = {};
+    if (live) m = meta[c];
     const u32 nbSeq = m.nbSeq, n = m.srcSize;
     // Multi-block frames (row f-1): chunk c is block bf of frame c / frameBlocks.  A later block never relies on the repcodes the
     // blocks before it leave behind — whether one of them ends up stored raw (and so leaves the decoder's history untouched,
@@ -280,41 +284,78 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     tLLlog = uniform(tLLlog); tOFlog = uniform(tOFlog); tMLlog = uniform(tMLlog); tLastCount = uniform(tLastCount);
     u32 bitstreamSize = 0;
     ZMI_ESTAMP(2);
-    if (typesOk) {
-        // ZSTD_encodeSequences_body (U/ZstdCompressSequences.cs:585-704), 64 sequences per step, last sequence first:
-        //   lanes 0/1/2 run the LL / OF / ML state chains (they are independent of each other: a state only depends on
-        //   its own previous state and symbol), every lane then packs the bit fields of ONE sequence in the reference's
-        //   order [OF state, ML state, LL state, LL extra, ML extra, OF extra]; a wave prefix sum places them.
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+    {
+        // ZSTD_encodeSequences_body (U/ZstdCompressSequences.cs:585-704), 64 sequences per step, last sequence first.  Every wave
+        // prepares the batch of its own chunk (codes and their symbol transforms, one sequence per lane) and later packs that
+        // batch's bit fields in the reference's order [OF state, ML state, LL state, LL extra, ML extra, OF extra] (a wave prefix
+        // sum places them); in between, the state chains — serial, a handful of instructions per step whatever runs them — of
+        // ALL FOUR chunks of the workgroup run on twelve lanes of wave 0 (lane 3 w + t = chunk w, table t: LL, OF, ML), so a
+        // chain step is issued once per workgroup instead of once per chunk.  Two barriers per batch hand the LDS arrays over.
+        if (lane == 0) sBatchSeq[wave] = typesOk ? nbSeq : 0u;
+        __syncthreads();
+        const u32 mySeq = typesOk ? nbSeq : 0u;
+        const u32 q0 = sBatchSeq[0], q1 = sBatchSeq[1], q2 = sBatchSeq[2], q3 = sBatchSeq[3];
+        const u32 q01 = q0 > q1 ? q0 : q1, q23 = q2 > q3 ? q2 : q3, maxSeq = q01 > q23 ? q01 : q23;       // uniform over the workgroup
         u8* const out = body + bodyTablesEnd;
-        const u16* const stT = lane == 0 ? W.llState : lane == 1 ? W.ofState : W.mlState;
-        const SymTT* const ttT = lane == 0 ? W.llTT : lane == 1 ? W.ofTT : W.mlTT;
+        // chain lanes (wave 0): their chunk's tables
+        const u32 cw = lane < 12 ? lane / 3 : 0, ct = lane < 12 ? lane % 3 : 0;
+        SeqWaveLds& CW = Ws[cw];
+        const u16* const stT = ct == 0 ? CW.llState : ct == 1 ? CW.ofState : CW.mlState;
+        const SymTT* const ttT = ct == 0 ? CW.llTT : ct == 1 ? CW.ofTT : CW.mlTT;
+        const u32 chainSeq = (wave == 0 && lane < 12) ? sBatchSeq[cw] : 0u;
         u32 state = 0;
         u32 carry = 0, carryBits = 0, outWords = 0;
-        for (u32 done = 0; done < nbSeq; done += 64) {
-            const u32 cnt = nbSeq - done < 64 ? nbSeq - done : 64;
+        for (u32 done = 0; done < maxSeq; done += 64) {
+            const bool act = done < mySeq;                      // uniform per wave
+            const u32 cnt = act ? (mySeq - done < 64 ? mySeq - done : 64) : 0;
             const bool have = lane < cnt;
             Seq sv; sv.offBase = 1; sv.litLength = 0; sv.mlBase = 0;
             if (have) sv = sq[nbSeq - 1 - done - lane];
             const u32 llc = ll_code(sv.litLength), ofc = highbit32(sv.offBase), mlc = ml_code(sv.mlBase);
-            W.bCode[0][lane] = (u8)llc; W.bCode[1][lane] = (u8)ofc; W.bCode[2][lane] = (u8)mlc;
-            for (u32 i = lane; i < 192; i += 64) W.tile[i] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            if (act) {
+                W.bCode[0][lane] = (u8)llc; W.bCode[1][lane] = (u8)ofc; W.bCode[2][lane] = (u8)mlc;
+                W.bTT[0][lane] = W.llTT[llc]; W.bTT[1][lane] = W.ofTT[ofc]; W.bTT[2][lane] = W.mlTT[mlc];
+                for (u32 i = lane; i < 192; i += 64) W.tile[i] = 0;
+            }
+            __syncthreads();
             ZMI_ESTAMP(3);
-            if (lane < 3) {
-                for (u32 k = 0; k < cnt; k++) {
-                    const u32 sym = W.bCode[lane][k];
-                    if (done == 0 && k == 0) { state = fse_init_state2(stT, ttT, sym); W.bBits[lane][k] = 0; }   // FSE_initCState2: no bits
-                    else {
-                        const SymTT tt = ttT[sym];
-                        const u32 nb = (state + tt.deltaNbBits) >> 16;
-                        W.bBits[lane][k] = (state & ((1u << nb) - 1)) | (nb << 16);
-                        state = stT[(s32)(state >> nb) + tt.deltaFindState];
+            if (done < chainSeq) {
+                // a chain step is: nb = (state + deltaNbBits) >> 16, emit the low nb bits, state = table[(state >> nb) + deltaFindState]
+                // (FSE_encodeSymbol, U/Fse.cs:41-49); the transforms come four at a time, ahead of the states that need them
+                const u32 ccnt = chainSeq - done < 64 ? chainSeq - done : 64;
+                u32 k = 0;
+                if (done == 0) { state = fse_init_state2(stT, ttT, CW.bCode[ct][0]); CW.bBits[ct][0] = 0; k = 1; }   // FSE_initCState2: no bits
+                for (; k < ccnt && (k & 3); k++) {
+                    const SymTT tt = CW.bTT[ct][k];
+                    const u32 nb = (state + tt.deltaNbBits) >> 16;
+                    CW.bBits[ct][k] = (state & ((1u << nb) - 1)) | (nb << 16);
+                    state = stT[(s32)(state >> nb) + tt.deltaFindState];
+                }
+                for (; k < ccnt; k += 4) {              // k is a multiple of 4: the four transforms lie inside the batch's 64 slots
+                    const SymTT t0 = CW.bTT[ct][k], t1 = CW.bTT[ct][k + 1], t2 = CW.bTT[ct][k + 2], t3 = CW.bTT[ct][k + 3];
+                    u32 nb = (state + t0.deltaNbBits) >> 16;
+                    CW.bBits[ct][k] = (state & ((1u << nb) - 1)) | (nb << 16);
+                    state = stT[(s32)(state >> nb) + t0.deltaFindState];
+                    if (k + 1 < ccnt) {
+                        nb = (state + t1.deltaNbBits) >> 16;
+                        CW.bBits[ct][k + 1] = (state & ((1u << nb) - 1)) | (nb << 16);
+                        state = stT[(s32)(state >> nb) + t1.deltaFindState];
+                    }
+                    if (k + 2 < ccnt) {
+                        nb = (state + t2.deltaNbBits) >> 16;
+                        CW.bBits[ct][k + 2] = (state & ((1u << nb) - 1)) | (nb << 16);
+                        state = stT[(s32)(state >> nb) + t2.deltaFindState];
+                    }
+                    if (k + 3 < ccnt) {
+                        nb = (state + t3.deltaNbBits) >> 16;
+                        CW.bBits[ct][k + 3] = (state & ((1u << nb) - 1)) | (nb << 16);
+                        state = stT[(s32)(state >> nb) + t3.deltaFindState];
                     }
                 }
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
+            __syncthreads();
             ZMI_ESTAMP(4);
+            if (!act) continue;                                 // uniform per wave; the barriers above are met by every wave
             u64 lo = 0, hi = 0; u32 nbTot = 0;
             auto put = [&](u32 v, u32 nb) {
                 if (!nb) return;
@@ -352,9 +393,11 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         }
         ZMI_ESTAMP(3);
+        if (wave == 0 && lane < 12) sFinalState[cw][ct] = state;
+        __syncthreads();
         // FSE_flushCState x3 (ML, OF, LL) + end mark (BIT_closeCStream)
-        const u32 stLL = read_lane(state, 0), stOF = read_lane(state, 1), stML = read_lane(state, 2);
-        if (lane == 0) {
+        if (typesOk && lane == 0) {
+            const u32 stLL = sFinalState[wave][0], stOF = sFinalState[wave][1], stML = sFinalState[wave][2];
             u64 acc = carry; u32 nb = carryBits;
             acc |= (u64)(stML & ((1u << tMLlog) - 1)) << nb; nb += tMLlog;
             acc |= (u64)(stOF & ((1u << tOFlog) - 1)) << nb; nb += tOFlog;
@@ -370,7 +413,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
 #ifdef ZMI_LZ_STAMPS
     if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_sencStamps[i], stampAcc[i]);
 #endif
-    if (lane != 0) return;
+    if (lane != 0 || !live) return;
     if (typesOk) {
         op = body + bodyTablesEnd + bitstreamSize;
         const u32 lastCountSize = tLastCount;
