@@ -122,15 +122,26 @@ __device__ __forceinline__ u32 lds_load4(const u8* base, u32 pos)
     return __builtin_amdgcn_alignbyte(w32[1], w32[0], pos & 3);
 }
 
-// length of the match between position p (its first 8 bytes are w) and cpos < p, capped; 0 if shorter than 4
-__device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w, u32 n)
+// 16 input bytes at an arbitrary LDS position: five aligned dwords, four v_alignbyte
+__device__ __forceinline__ void lds_load16(const u8* base, u32 pos, u64& lo, u64& hi)
 {
-    if (lds_load4(L.in, cpos) != (u32)w) return 0;          // the reference's MEM_read32 check (ZstdFast.cs:179-191)
-    u64 x = w ^ lds_load8(L.in, cpos);
-    u32 l = x ? (ctz64(x) >> 3) : 8;
-    if (!x) {
+    const u32* w32 = reinterpret_cast<const u32*>(base) + (pos >> 2);
+    const u32 sh = pos & 3, d0 = w32[0], d1 = w32[1], d2 = w32[2], d3 = w32[3], d4 = w32[4];
+    lo = (u64)__builtin_amdgcn_alignbyte(d1, d0, sh) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, sh) << 32);
+    hi = (u64)__builtin_amdgcn_alignbyte(d3, d2, sh) | ((u64)__builtin_amdgcn_alignbyte(d4, d3, sh) << 32);
+}
+
+// length of the match between position p (its first 16 bytes are w, w2) and cpos < p, capped; 0 if shorter than 4 (the reference's
+// MEM_read32 check, ZstdFast.cs:179-191).  The first 16 bytes are compared without a branch; only longer matches loop.
+__device__ __forceinline__ u32 match_len(const LzLds& L, u32 p, u32 cpos, u64 w, u64 w2, u32 n)
+{
+    u64 c1, c2;
+    lds_load16(L.in, cpos, c1, c2);
+    const u64 x1 = w ^ c1, x2 = w2 ^ c2;
+    u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
+    if (l == 16) {
         while (l < kLenCap) {
-            x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
+            const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
             if (x) { l += ctz64(x) >> 3; break; }
             l += 8;
         }
@@ -195,7 +206,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     const u32 nData = (u32)((srcSize - base) < cb ? (srcSize - base) : cb);
     const u32 n = hist + nData;                            // end of the data in LDS
 #ifdef ZMI_LZ_STAMPS
-    unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
+    unsigned long long stampAcc[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
 
     // ---- stage the chunk: 16 B per lane when the source is 16-byte aligned ----
@@ -371,14 +382,14 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         auto arr_ix = [&](u32 j, u32 q) -> u32 { return super ? j * kTile + tid : q; };
         // ---------------- probe ----------------
         // fast: h = hash product, cand = table entry.  dual: h = long product, h2 = short product, cand = tableL | tableS << 16
-        u64 w[kPPT]; u32 h[kPPT], h2[kPPT], cand[kPPT]; bool valid[kPPT];
+        u64 w[kPPT], w2[kPPT]; u32 h[kPPT], h2[kPPT], cand[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = probed(j), p = tileStart + q;
-            valid[j] = j < nPass && j * kTile + tid < slots && p + 8 <= n && p >= lowLimit; w[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
+            valid[j] = j < nPass && j * kTile + tid < slots && p + 8 <= n && p >= lowLimit; w[j] = 0; w2[j] = 0; h[j] = 0; h2[j] = 0; cand[j] = 0;
             if (j >= nPass) continue;            // uniform
             if (valid[j]) {
-                w[j] = lds_load8(L.in, p);
+                lds_load16(L.in, p, w[j], w2[j]);
                 if (MODE == 0) {
                     h[j] = hash6p(w[j]);
                     cand[j] = table[hidx(h[j])];
@@ -427,7 +438,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     }
                 }
                 if (MODE == 0) {
-                    if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
+                    if (per) { len = match_len(L, p, p - per, w[j], w2[j], n); off = per; }
                     else {
                         // (2) same-tile first occurrence, (3) latest occurrence in earlier tiles: keep the longer, nearer on ties
                         const u32 tag = htag(h[j]);
@@ -435,18 +446,18 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                         const u32 fq = (f >> 16) - stamp;                 // (an entry seen here was written by this tile: see `stamp`)
                         if (!fused && fq < q && (f & 0xFFFFu) == tag) {
                             const u32 cpos = tileStart + fq;
-                            len = match_len(L, p, cpos, w[j], n); off = p - cpos;
+                            len = match_len(L, p, cpos, w[j], w2[j], n); off = p - cpos;
                         }
                         if (FAR) {
                             if (cand[j] && (cand[j] & 0x3FFFu) == (tag >> 2) && len < kLenCap) {
                                 const u32 crel = (cand[j] >> 14) - 1;                 // kFarMax + position; below kFarMax: in front of the block
-                                const u32 l2 = crel >= kFarMax ? match_len(L, p, crel - kFarMax, w[j], n)
+                                const u32 l2 = crel >= kFarMax ? match_len(L, p, crel - kFarMax, w[j], w2[j], n)
                                                                : match_len_far(L, p, in - (kFarMax - crel), w[j], n);
                                 if (l2 > len) { len = l2; off = kFarMax + p - crel; }
                             }
                         } else if (cand[j] && (cand[j] & 0xFFFFu) == tag && len < kLenCap) {
                             const u32 cpos = (cand[j] >> 16) - 1;
-                            const u32 l2 = match_len(L, p, cpos, w[j], n);
+                            const u32 l2 = match_len(L, p, cpos, w[j], w2[j], n);
                             if (l2 > len) { len = l2; off = p - cpos; }
                         }
                     }
@@ -458,30 +469,30 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     // entry, no atomic (two positions with the same 13-bit hash share the 12-bit bucket)
                     if (fL == stamp + q) tableL[hL] = (u16)(p + 1);
                     if (fS == stamp + q) tableS[hS] = (u16)(p + 1);
-                    if (per) { len = match_len(L, p, p - per, w[j], n); off = per; }
+                    if (per) { len = match_len(L, p, p - per, w[j], w2[j], n); off = per; }
                     // candidates, longest wins, nearer on ties: in-tile long, earlier-tile long, in-tile short, earlier-tile short
                     u32 c0p = 0xFFFFFFFFu, c1p = 0xFFFFFFFFu;
                     if (len < kLenCap && fL - stamp < q && (eL & 0xFFFFu) == htag(h[j])) {
                         c0p = tileStart + (fL - stamp);
-                        const u32 l2 = match_len(L, p, c0p, w[j], n);
+                        const u32 l2 = match_len(L, p, c0p, w[j], w2[j], n);
                         if (l2 > len || (l2 == len && l2 && p - c0p < off)) { len = l2; off = p - c0p; }
                     }
                     if (len < kLenCap && (cand[j] & 0xFFFFu)) {
                         c1p = (cand[j] & 0xFFFFu) - 1;
-                        const u32 l2 = match_len(L, p, c1p, w[j], n);
+                        const u32 l2 = match_len(L, p, c1p, w[j], w2[j], n);
                         if (l2 > len) { len = l2; off = p - c1p; }
                     }
                     if (len < kLenCap && fS - stamp < q && (eS & 0xFFFFu) == htag(h2[j])) {
                         const u32 cp = tileStart + (fS - stamp);
                         if (cp != c0p) {
-                            const u32 l2 = match_len(L, p, cp, w[j], n);
+                            const u32 l2 = match_len(L, p, cp, w[j], w2[j], n);
                             if (l2 > len || (l2 == len && l2 && p - cp < off)) { len = l2; off = p - cp; }
                         }
                     }
                     if (len < kLenCap && (cand[j] >> 16)) {
                         const u32 cp = (cand[j] >> 16) - 1;
                         if (cp != c1p) {
-                            const u32 l2 = match_len(L, p, cp, w[j], n);
+                            const u32 l2 = match_len(L, p, cp, w[j], w2[j], n);
                             if (l2 > len) { len = l2; off = p - cp; }
                         }
                     }
@@ -589,7 +600,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (lane == 0) *segExit0 = z;
                 }
             }
+            ZMI_STAMP(10);
             __syncthreads();
+            ZMI_STAMP(11);
             if (wave >= w0) {                                                 // (uniform) earlier waves lie before the cursor: nothing selected
                 u32 ent = e0, kStart = k0;
                 if (wave > w0) {
@@ -600,6 +613,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #pragma unroll
                     for (u32 k = 1; k < 15; ++k) if (k > w0 && k < wave) ent = read_lane(fv[k], ent);
                 }
+                ZMI_STAMP(12);
 #pragma unroll
                 for (u32 k = 0; k < 4; ++k) {
                     if (k < kStart) continue;                                 // uniform
@@ -611,6 +625,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (lane == 0) L.selMask[wave * 4 + k] = mark;
                 }
             }
+            ZMI_STAMP(13);
             __syncthreads();
             ZMI_STAMP(8);
             if (wave == 0) {
@@ -795,7 +810,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(7);
     }
 #ifdef ZMI_LZ_STAMPS
-    if ((tid & 63u) == 0) for (int i = 0; i < 10; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
+    if ((tid & 63u) == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
 #endif
     if (tid == 0) {
         ChunkMeta m = {};
