@@ -36,17 +36,26 @@ extern "C" void ZSTDMI_debugReadSeqStamps(unsigned long long* out16, int reset)
 //   B  wave 0 walks the chains, lane s = block s — kPack sequences per instruction, each lane with its own table slot in
 //      LDS and its own bit window — and leaves one (states, bit position) record per sequence, 64 sequences per block at a time;
 //   C  waves 1-3 turn the records of the PREVIOUS 64 sequences of each block into SeqRecs meanwhile (fields, repcodes, prefix
-//      sums: 64 lanes per block), two blocks per wave; one barrier per 64 sequences hands the record buffers over.
-constexpr u32 kPack = 6;                 // 6 x 5 KiB of tables + records: four workgroups per CU
+//      sums: 64 lanes per block), and keep each block's bitstream staged in an LDS ring ahead of its chain (a global load in
+//      the chain costs it several hundred cycles per sequence, an LDS read rides along with the table reads); one barrier
+//      per 64 sequences hands the record buffers and the ring positions over.
+constexpr u32 kPack = 5;                 // 5 x (5 KiB of tables + 2 KiB of stream + records): four workgroups per CU
+constexpr u32 kRing = 2048, kRingDw = kRing / 4;
 constexpr u32 kTabLL = 0, kTabML = 512, kTabOF = 1024, kTabWords = 1280;
 
 struct SeqLds {
     u32 tab[kPack][kTabWords];           // one entry per state: nextState:16 | nbBits:4 (bit 16) | nbAddBits:5 (bit 20) | symbol:6 (bit 25)
     u32 recSt[2][kPack][64];             // phase B -> C (double-buffered): the three states before each of a block's 64 sequences ...
-    s32 recPos[2][kPack][64];            // ... and the bit position
-    s16 norm[4][64];                     // table-build scratch, one per wave
-    u16 symbolNext[4][64];
-    u32 logs[kPack];                     // llLog | ofLog << 8 | mlLog << 16, or 0xFFFFFFFF: some table of the block is corrupt
+    u16 recPos[2][kPack][64];            // ... and the bit position, as posBase - position
+    s32 posBase[2][kPack];               // bit position at the start of the batch
+    // the stream of block s: byte x (from the stream's start) lives at ring[s][x & 2047] while it is staged.  ringLo = lowest
+    // staged byte the chain may rely on in a batch, curByte = byte the chain stands at when a batch starts (both double-buffered:
+    // written during one batch for the next)
+    union {
+        u32 ring[kPack][kRingDw];
+        struct { s16 norm[4][64]; u16 symbolNext[4][64]; } build;     // table-build scratch, one per wave (phase A only)
+    };
+    s32 ringLo[2][kPack], curByte[2][kPack];
     u32 tblErr[kPack][3];
     u32 chainErr[kPack];
     s32 endPos[kPack];
@@ -183,7 +192,7 @@ __device__ __forceinline__ void seq_fields_batch(const SeqLds& L, u32 buf, u32 s
         const u32 qLL = T[kTabLL + (st & 1023u)], qML = T[kTabML + ((st >> 10) & 1023u)], qOF = T[kTabOF + (st >> 20)];
         const u32 aLL = (qLL >> 20) & 31u, aML = (qML >> 20) & 31u, aOF = (qOF >> 20) & 31u;
         const u32 bLL = dLL_base[qLL >> 25], bML = dML_base[qML >> 25], bOF = of_base(qOF >> 25);
-        s32 p = L.recPos[buf][sl][lane];
+        s32 p = L.posBase[buf][sl] - (s32)L.recPos[buf][sl][lane];
         const u32 ofv = stream_field(sp, size, p, aOF); p -= (s32)aOF;
         const u32 mlv = stream_field(sp, size, p, aML); p -= (s32)aML;
         const u32 llv = stream_field(sp, size, p, aLL);
@@ -255,9 +264,9 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
                     d = src + S.srcOff + o; avail = uniform(S.bsz) - o;
                 }
                 u32 lg;
-                if (t == 0)      lg = set_seq_table(L.norm[wave], L.symbolNext[wave], L.tab[sl] + kTabLL, mode, 35, 9, d, avail, 0, dLL_defaultNorm, 6, 35, lane);
-                else if (t == 1) lg = set_seq_table(L.norm[wave], L.symbolNext[wave], L.tab[sl] + kTabOF, mode, 31, 8, d, avail, 1, dOF_defaultNorm, 5, 28, lane);
-                else             lg = set_seq_table(L.norm[wave], L.symbolNext[wave], L.tab[sl] + kTabML, mode, 52, 9, d, avail, 2, dML_defaultNorm, 6, 52, lane);
+                if (t == 0)      lg = set_seq_table(L.build.norm[wave], L.build.symbolNext[wave], L.tab[sl] + kTabLL, mode, 35, 9, d, avail, 0, dLL_defaultNorm, 6, 35, lane);
+                else if (t == 1) lg = set_seq_table(L.build.norm[wave], L.build.symbolNext[wave], L.tab[sl] + kTabOF, mode, 31, 8, d, avail, 1, dOF_defaultNorm, 5, 28, lane);
+                else             lg = set_seq_table(L.build.norm[wave], L.build.symbolNext[wave], L.tab[sl] + kTabML, mode, 52, 9, d, avail, 2, dML_defaultNorm, 6, 52, lane);
                 res = lg == 0xFFFFFFFFu ? ((s == kDictBlock ? (u32)kErrDictionaryCorrupted : (u32)kErrCorruption) << 8) | 0xFFu : lg;
             }
         }
@@ -293,10 +302,10 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
     }
     const u32 maxSeq = wave_max(mNbSeq);                            // (the same in every wave)
     const u32 nBatch = (maxSeq + 63) >> 6;
-    // phase C: wave w (1..3) owns slots w - 1 and w + 2
-    const u32 slA = wave ? wave - 1 : 0, slB = wave ? wave + 2 : 0;
+    // phase C: wave w (1..3) owns slots w - 1 and w + 2 (the latter only while it exists)
+    const u32 slA = wave ? wave - 1 : 0, slB = (wave && wave + 2 < kPack) ? wave + 2 : kPack;      // kPack = none
     SlotState SA = { { 1, 0 }, { 2, 0 }, { 3, 0 }, 0, 0, 0 }, SB = SA;       // the block's starting repcodes, symbolically
-    const u32 nbA = read_lane(mNbSeq, slA), nbB = read_lane(mNbSeq, slB);
+    const u32 nbA = read_lane(mNbSeq, slA), nbB = slB < kPack ? read_lane(mNbSeq, slB) : 0u;
     const u8* const spA = reinterpret_cast<const u8*>(read_lane64((u64)(uintptr_t)mSp, slA));
     const u8* const spB = reinterpret_cast<const u8*>(read_lane64((u64)(uintptr_t)mSp, slB));
     const s32 sizeA = (s32)read_lane((u32)mSize, slA), sizeB = (s32)read_lane((u32)mSize, slB);
@@ -304,6 +313,17 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
     SeqRec* __restrict__ const recA = recs + read_lane64(mSeqBase, slA);
     SeqRec* __restrict__ const recB = recs + read_lane64(mSeqBase, slB);
     const u32* const mT = L.tab[lane < kPack ? lane : 0];
+    // ---- the top 2 KiB of every stream into its ring (zeros outside the stream) ----
+    s32 loA = 0, loB = 0;                                           // helper waves: lowest staged byte of their blocks (multiples of 4)
+    auto stage = [&](u32 sl, const u8* sp, s32 size, s32 from, s32 to) {       // bytes [from, to), multiples of 4
+        for (s32 x = from + 4 * (s32)lane; x < to; x += 256) L.ring[sl][(u32)(x >> 2) & (kRingDw - 1)] = stream_dword_z(sp, size, x >> 2);
+    };
+    if (wave) {
+        if (nbA) { const s32 hi = (sizeA + 3) & ~3; loA = hi - (s32)kRing; stage(slA, spA, sizeA, loA, hi); }
+        if (nbB) { const s32 hi = (sizeB + 3) & ~3; loB = hi - (s32)kRing; stage(slB, spB, sizeB, loB, hi); }
+        if (lane == 0) { L.ringLo[0][slA] = loA; if (slB < kPack) L.ringLo[0][slB] = loB; }
+    } else if (lane < kPack) L.curByte[0][lane] = pos >> 3;
+    __syncthreads();
     for (u32 bt = 0; bt <= nBatch; ++bt) {
         const u32 base = bt << 6;
         if (wave == 0) {
@@ -312,15 +332,22 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
             // one cache line for a dozen sequences); the extra-bit fields are only skipped here ----
             if (base < mNbSeq) {
                 const u32 steps = mNbSeq - base < 64 ? mNbSeq - base : 64, buf = bt & 1;
+                const s32 ringLo = L.ringLo[buf][lane], pos0 = pos;
+                const u32* const R = L.ring[lane];
+                L.posBase[buf][lane] = pos0;
                 for (u32 k = 0; k < steps; ++k) {
                     const u32 eLL = mT[kTabLL + sLL], eML = mT[kTabML + sML], eOF = mT[kTabOF + sOF];
                     const s32 dl = ((pos - 1) >> 5) - 3;                // the window: stream dwords dl .. dl + 3, at least bits [pos - 97, pos)
                     u32 w0, w1, w2, w3;
+                    if (4 * dl >= ringLo) {                             // staged (always, unless a damaged stream runs away below its start)
+                        const u32 ix0 = (u32)dl & (kRingDw - 1);
+                        w0 = R[ix0]; w1 = R[(ix0 + 1) & (kRingDw - 1)]; w2 = R[(ix0 + 2) & (kRingDw - 1)]; w3 = R[(ix0 + 3) & (kRingDw - 1)];
+                    } else
                     if (dl >= 0 && 4 * dl + 16 <= mSize) {
                         const u64 a = readLE64(mSp + 4 * dl), b = readLE64(mSp + 4 * dl + 8);
                         w0 = (u32)a; w1 = (u32)(a >> 32); w2 = (u32)b; w3 = (u32)(b >> 32);
                     } else { w0 = stream_dword_z(mSp, mSize, dl); w1 = stream_dword_z(mSp, mSize, dl + 1); w2 = stream_dword_z(mSp, mSize, dl + 2); w3 = stream_dword_z(mSp, mSize, dl + 3); }
-                    L.recSt[buf][lane][k] = sLL | (sML << 10) | (sOF << 20); L.recPos[buf][lane][k] = pos;
+                    L.recSt[buf][lane][k] = sLL | (sML << 10) | (sOF << 20); L.recPos[buf][lane][k] = (u16)(pos0 - pos);
                     const u32 nLL = (eLL >> 16) & 15u, nML = (eML >> 16) & 15u, nOF = (eOF >> 16) & 15u, nbTot = nLL + nML + nOF;
                     const s32 q = pos - (s32)(((eLL >> 20) & 31u) + ((eML >> 20) & 31u) + ((eOF >> 20) & 31u)) - (s32)nbTot;
                     const u32 rr = (u32)(q - 32 * dl), ix = rr >> 5;     // q >= pos - 89 >= 32 dl + 8
@@ -333,11 +360,20 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
                     pos = q;
                 }
             }
-        } else if (bt) {
-            // ---- phase C for the previous 64 sequences of this wave's two blocks ----
-            const u32 pbase = base - 64, buf = (bt - 1) & 1;
-            if (pbase < nbA && !SA.err) seq_fields_batch(L, buf, slA, pbase, nbA, spA, sizeA, litA, recA, SA, lane);
-            if (pbase < nbB && !SB.err) seq_fields_batch(L, buf, slB, pbase, nbB, spB, sizeB, litB, recB, SB, lane);
+            if (lane < kPack) L.curByte[(bt + 1) & 1][lane] = pos >> 3;
+        } else {
+            // ---- phase C for the previous 64 sequences of this wave's blocks ----
+            if (bt) {
+                const u32 pbase = base - 64, buf = (bt - 1) & 1;
+                if (pbase < nbA && !SA.err) seq_fields_batch(L, buf, slA, pbase, nbA, spA, sizeA, litA, recA, SA, lane);
+                if (pbase < nbB && !SB.err) seq_fields_batch(L, buf, slB, pbase, nbB, spB, sizeB, litB, recB, SB, lane);
+            }
+            // ---- their streams: stage down to 2 KiB below where the chain stands now.  What that overwrites in the ring lies 16
+            // bytes or more above the chain's position (dead: it only moves down); a batch consumes at most 712 bytes and the
+            // chain reaches 16 below its position, so the NEXT batch finds everything it can touch staged by this one ----
+            if (nbA) { s32 nl = (L.curByte[bt & 1][slA] + 16 - (s32)kRing + 3) & ~3; if (nl < -64) nl = -64; if (nl < loA) { stage(slA, spA, sizeA, nl, loA); loA = nl; } }
+            if (nbB) { s32 nl = (L.curByte[bt & 1][slB] + 16 - (s32)kRing + 3) & ~3; if (nl < -64) nl = -64; if (nl < loB) { stage(slB, spB, sizeB, nl, loB); loB = nl; } }
+            if (lane == 0) { L.ringLo[(bt + 1) & 1][slA] = loA; if (slB < kPack) L.ringLo[(bt + 1) & 1][slB] = loB; }
         }
         __syncthreads();
     }
@@ -350,7 +386,7 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
         for (u32 h = 0; h < 2; ++h) {
             const u32 sl = h ? slB : slA; const SlotState& S = h ? SB : SA;
             const u32 bi = b0 + sl;
-            if (bi >= nBlocks) continue;
+            if (sl >= kPack || bi >= nBlocks) continue;
             BlockDesc& B = blocks[bi];
             if (B.type != 2 || B.nbSeq == 0 || B.err) continue;
             u32 err = L.chainErr[sl];                               // tables, end mark
