@@ -21,11 +21,15 @@ def main():
     comps = {}; decs = {}
     while time.time() - t0 < budget:
         kind = rng.choice(kinds); level = rng.choice([1, 1, 3, 5]); chk = rng.randrange(2); dk = rng.choice(list(dicts))
-        n = rng.choice([rng.randrange(0, 300), rng.randrange(0, 70000), rng.randrange(0, 400000), 65536 * rng.randrange(1, 5) + rng.randrange(-2, 3)])
+        n = rng.choice([rng.randrange(0, 300), rng.randrange(0, 70000), rng.randrange(0, 400000), 65536 * rng.randrange(1, 5) + rng.randrange(-2, 3),
+                        32768 * rng.randrange(1, 40) + rng.randrange(-2, 3)])
         data = datagen.gen(kind, n, rng.randrange(1 << 30))
-        key = (level, chk, dk)
+        # cross-chunk history (row f-1): by level, off, or 16/32/48 KiB with frames of 128 KiB .. 1 MiB
+        hist = rng.choice([(-1, 0), (-1, 0), (0, 0), (16 << 10, 128 << 10), (32 << 10, 256 << 10), (48 << 10, 1 << 20), (32 << 10, 64 << 10)])
+        key = (level, chk, dk, hist)
         if key not in comps:
             c = z.Compressor(level); c.SetParameter(201, chk); c.LoadDictionary(dicts[dk]); comps[key] = c
+            assert z._ffi.load().ZSTDMI_CCtx_setHistory(c.cctx, hist[0], hist[1]) == 0
         if dk not in decs:
             d = z.Decompressor(); d.LoadDictionary(dicts[dk]); decs[dk] = d
         c, d = comps[key], decs[dk]
