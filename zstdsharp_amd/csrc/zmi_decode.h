@@ -345,12 +345,24 @@ __device__ __forceinline__ void wave_copy(u8* __restrict__ d, const u8* __restri
     if (lane < n - done) d[done + lane] = s[done + lane];
 }
 // exact n-byte copy by ONE lane in 8-byte pieces (the last piece overlaps the one before instead of a byte tail);
-// source and destination do not overlap
+// source and destination do not overlap.  Four pieces are loaded before the first is stored: a copy of up to 32 bytes costs one
+// load latency, not one per piece (the lanes of a wave copy different runs, so this latency is what the wave waits for).
 __device__ __forceinline__ void lane_copy(u8* __restrict__ d, const u8* __restrict__ s, u32 n)
 {
-    if (n >= 8) {
-        for (u32 i = 0; i + 8 < n; i += 8) *(u64u*)(d + i) = readLE64(s + i);
-        *(u64u*)(d + n - 8) = readLE64(s + n - 8);
+    if (n >= 8 && n <= 16) {               // the common short run: two pieces
+        const u64 a0 = readLE64(s), a1 = readLE64(s + n - 8);
+        *(u64u*)d = a0; *(u64u*)(d + n - 8) = a1;
+    } else if (n > 16) {
+        u32 i = 0;
+        for (; i + 32 < n; i += 32) {
+            const u64 a0 = readLE64(s + i), a1 = readLE64(s + i + 8), a2 = readLE64(s + i + 16), a3 = readLE64(s + i + 24);
+            *(u64u*)(d + i) = a0; *(u64u*)(d + i + 8) = a1; *(u64u*)(d + i + 16) = a2; *(u64u*)(d + i + 24) = a3;
+        }
+        // the last 1..32 bytes: pieces at i, i + 8, i + 16 (each pulled back to n - 8 where it would overrun) and n - 8
+        const u32 e = n - 8;
+        const u32 o0 = i < e ? i : e, o1 = i + 8 < e ? i + 8 : e, o2 = i + 16 < e ? i + 16 : e;
+        const u64 a0 = readLE64(s + o0), a1 = readLE64(s + o1), a2 = readLE64(s + o2), a3 = readLE64(s + e);
+        *(u64u*)(d + o0) = a0; *(u64u*)(d + o1) = a1; *(u64u*)(d + o2) = a2; *(u64u*)(d + e) = a3;
     } else if (n >= 4) {
         const u32 a = readLE32(s), b = readLE32(s + n - 4);
         *(u32u*)d = a; *(u32u*)(d + n - 4) = b;
@@ -366,8 +378,15 @@ __device__ __forceinline__ void lane_match_copy(u8* d, u32 offset, u32 n)
     const u8* s0 = d - offset;
     if (offset >= n) { lane_copy(d, s0, n); return; }
     if (offset >= 8) {
-        // n > offset >= 8: pieces in order, each reading bytes that earlier pieces of this lane have written
+        // n > offset >= 8: pieces in order, each reading bytes that earlier pieces of this lane have written; with a distance of
+        // 32 or more, four pieces at a time only read what earlier groups wrote
         u32 i = 0;
+        if (offset >= 32) {
+            for (; i + 32 <= n; i += 32) {
+                const u64 a0 = readLE64(s0 + i), a1 = readLE64(s0 + i + 8), a2 = readLE64(s0 + i + 16), a3 = readLE64(s0 + i + 24);
+                *(u64u*)(d + i) = a0; *(u64u*)(d + i + 8) = a1; *(u64u*)(d + i + 16) = a2; *(u64u*)(d + i + 24) = a3;
+            }
+        }
         for (; i + 8 <= n; i += 8) *(u64u*)(d + i) = readLE64(s0 + i);
         for (; i < n; i++) d[i] = s0[i];
         return;
