@@ -439,11 +439,15 @@ __global__ __launch_bounds__(64) void place_literals_kernel(const u8* __restrict
     else rleByte = src[B.srcOff + B.lhSize];
     u32 litPos = 0, outEnd = 0;
     const SeqRec* __restrict__ const rec = recs + B.seqBase;
+    SeqRec rNext; rNext.off = 1; rNext.llTag = 0; rNext.ml = 0; rNext.pos = 0;
+    if (lane < nbSeq) rNext = rec[lane];                        // records come one batch ahead
     for (u32 base = 0; base < nbSeq; base += 64) {
         const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
         const bool have = lane < cnt;
         u32 ll = 0, ml = 0, pos = 0;
-        if (have) { const SeqRec r = rec[base + lane]; ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; }
+        const SeqRec r = rNext;
+        if (base + 64 + lane < nbSeq) rNext = rec[base + 64 + lane];
+        if (have) { ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; }
         const u32 inclLit = wave_scan_incl(ll);
         const u32 totalLit = read_lane(inclLit, 63);
         const u32 sLit = litPos + inclLit - ll;
@@ -526,12 +530,15 @@ __global__ __launch_bounds__(64) void exec_matches_kernel(const u8* __restrict__
         const u32 in0 = uniform(B.repIn[0]), in1 = uniform(B.repIn[1]), in2 = uniform(B.repIn[2]);
         const SeqRec* __restrict__ const rec = recs + B.seqBase;
         // output of earlier blocks (other waves' literals included: kernel boundary) and of this wave so far is visible
+        SeqRec rNext; rNext.off = 1; rNext.llTag = 0; rNext.ml = 0; rNext.pos = 0;
+        if (lane < nbSeq) rNext = rec[lane];                    // records come one batch ahead: their load rides under the copies
         for (u32 base = 0; base < nbSeq; base += 64) {
             const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
             const bool have = lane < cnt;
             u32 ll = 0, ml = 0, pos = 0, off = 1;
+            const SeqRec r = rNext;
+            if (base + 64 + lane < nbSeq) rNext = rec[base + 64 + lane];
             if (have) {
-                const SeqRec r = rec[base + lane];
                 ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; off = r.off;
                 const u32 tag = r.llTag >> 30;
                 if (tag) { const u32 in = tag == 1 ? in0 : tag == 2 ? in1 : in2; off = in > off ? in - off : 1u; }
