@@ -277,7 +277,8 @@ def main():
         return
     src, what = make_input(n, (1234 if args.input == "zipf" else 7) + rank)
     hist_on = args.history > 0 if args.history is not None else args.level >= 3
-    framing = ("256 KiB frames of " + ("64 KiB blocks, far matches up to 188 KiB back" if args.level < 3 else "32 KiB blocks behind 32 KiB of history")) if hist_on \
+    framing = ("256 KiB frames of " + ("64 KiB blocks, far matches up to 188 KiB back" if args.level < 3 else
+                                       "48 KiB blocks behind 16 KiB of history (240 KiB frames)" if args.level < 5 and args.history is None else "32 KiB blocks behind 32 KiB of history")) if hist_on \
         else "one zstd frame per chunk"
     workload = f"{args.size_mib} MiB {what} per GPU, level {args.level}, " + ("cross-chunk history" if hist_on else "64 KiB independent chunks")
     torch.cuda.synchronize()          # the library runs on its own stream: the input must be complete before the first call

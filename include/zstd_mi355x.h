@@ -127,8 +127,8 @@ size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* cctx, unsigned chunksPerPass);
 /* Cross-chunk history (the window ZSTD_compress_frameChunk's block loop carries from block to block, U/ZstdCompress.cs:4705-4807,
  * U/ZstdCompressInternal.cs:787-813): historyBytes > 0 makes the blocks 64 KiB - historyBytes long, each matching into the
  * historyBytes of input in front of it, and groups them into multi-block frames of frameBytes of content (0 = keep, default
- * 256 KiB); 0 = independent single-block 64 KiB frames; < 0 = by level (default: on with 32 KiB for strategies above fast,
- * i.e. levels >= 3, or when ZSTD_c_windowLog > 16 is set).  Ignored while a dictionary is loaded. */
+ * 256 KiB); 0 = independent single-block 64 KiB frames; < 0 = by level (default: 16 KiB at levels 3-4, 32 KiB at levels >= 5,
+ * off at levels 1-2 unless ZSTD_c_windowLog > 16 is set).  Ignored while a dictionary is loaded. */
 size_t ZSTDMI_CCtx_setHistory(ZSTD_CCtx* cctx, int historyBytes, unsigned frameBytes);
 
 /* literal (Huffman) decoder: 0 = chosen by frame count (default), 1 = serial, 4 lanes per frame (highest throughput when

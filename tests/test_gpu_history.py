@@ -125,8 +125,10 @@ def test_history_is_on_by_level_and_by_window_log_and_off_with_a_dictionary(gpu_
         assert frame_sizes(c)[0] == (256 << 10), "a window above 64 KiB was asked for"
         c.SetParameter(ZSTD_c_windowLog, 16)
         assert frame_sizes(c)[0] == 65536
+    with z.Compressor(5) as c:
+        assert frame_sizes(c)[0] == (256 << 10), "greedy and above: eight 32 KiB blocks behind 32 KiB of history"
     with z.Compressor(3) as c:
-        assert frame_sizes(c)[0] == (256 << 10), "strategies above fast (levels >= 3) carry history by default"
+        assert frame_sizes(c)[0] == 5 * (48 << 10), "strategies above fast (levels >= 3) carry history by default: doubleFast takes 48 KiB blocks behind 16 KiB"
         set_history(gpu_lib, c, 0)
         assert frame_sizes(c)[0] == 65536
         set_history(gpu_lib, c, -1)

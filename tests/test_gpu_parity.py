@@ -332,13 +332,14 @@ def test_level_finders_sequences_reconstruct_input(gpu_lib, level):
                 seqs, lits = _gpu_chunk(gpu_lib, c.cctx, idx)
                 assert _replay(seqs, lits, hi - lo) == data[lo:hi]
                 assert all(mlb + 3 >= 4 for _, _, mlb in seqs)
-            # the level's default: blocks of 32 KiB that match into the 32 KiB in front of them (row f-1); a later block's
+            # the level's default: blocks of 48 / 32 KiB that match into the 16 / 32 KiB in front of them (row f-1); a later block's
             # sequences replay against the frame so far and never lean on repcodes they did not define themselves
             assert gpu_lib.ZSTDMI_CCtx_setHistory(c.cctx, -1, 0) == 0
             c.Wrap(data)
             reach = 0
-            for idx, lo in enumerate(range(0, len(data), 32768)):
-                hi = min(lo + 32768, len(data))
+            bs = 49152 if level < 5 else 32768            # doubleFast levels: 48 KiB blocks behind 16 KiB of history; above: 32 + 32
+            for idx, lo in enumerate(range(0, len(data), bs)):
+                hi = min(lo + bs, len(data))
                 seqs, lits = _gpu_chunk(gpu_lib, c.cctx, idx)
                 assert _replay(seqs, lits, hi - lo, history=data[:lo], rep=(1, 4, 8) if idx == 0 else (0, 0, 0)) == data[lo:hi]
                 pos = 0
@@ -346,7 +347,7 @@ def test_level_finders_sequences_reconstruct_input(gpu_lib, level):
                     pos += ll
                     if off_base > 3: reach = max(reach, off_base - 3 - pos)
                     pos += mlb + 3
-            assert reach <= 32768, "history is the 32 KiB in front of the block"
+            assert reach <= 65536 - bs, "history is the 16 / 32 KiB in front of the block"
             if kind in ("text", "period"): assert reach > 0, "some match must reach in front of its block"
 
 
@@ -523,7 +524,7 @@ def test_level5_compress_at_size(gpu_lib, oracle):
         assert cs < 0.47 * n
     k = gpu_lib.ZSTD_findFrameCompressedSize(head, len(head))
     end = 0
-    for _ in range(16):                                              # the first 16 frames = 4 MiB (level 5: 256 KiB frames of 32 KiB blocks)
+    for _ in range(16):                                              # the first 16 frames = 4 MiB (level 5: 256 KiB frames of eight 32 KiB blocks)
         end += gpu_lib.ZSTD_findFrameCompressedSize(head[end:], len(head) - end)
     assert k > 0 and oracle.decompress(head[:end], 4 << 20) == data[:4 << 20]
 

@@ -123,8 +123,9 @@ struct ZSTD_CCtx_s {
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
     const u8* lastSrc = nullptr; u32 lastChunkBytes = 0;     // its source (debug hook: chunks without sequences keep their literals there)
     u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
-    // cross-chunk history (row f-1): -1 = by level (on for the strategies above fast, i.e. levels >= 3, and whenever the caller
-    // asks for a windowLog above 16), 0 = off (independent 64 KiB frames), else the bytes of history per block (4 KiB units)
+    // cross-chunk history (row f-1): -1 = by level (on for the strategies above fast, i.e. levels >= 3: 16 KiB at levels 3-4, 32 KiB
+    // above; and whenever the caller asks for a windowLog above 16), 0 = off (independent 64 KiB frames), else the bytes of
+    // history per block (4 KiB units)
     int historyBytes = -1; u32 frameBytes = 256u << 10;
     // streaming adapter (ZSTD_compressStream2): host-side batching in front of the one-shot engine
     std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
@@ -299,7 +300,9 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
     u32 frameBlocks = 0;
     if (prefixLen == 0 && srcSize > kChunkSize) {
         int hb = c->historyBytes;
-        if (hb < 0) hb = (rs.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (32 << 10) : 0;
+        // by level: the doubleFast levels (3-4; 3 is the library's default level) stage 16 KiB of history per 48 KiB block (one
+        // third more staging and hashing for three quarters of what 32 KiB buy), greedy and above 32 KiB per 32 KiB block
+        if (hb < 0) hb = (rs.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (rs.cp.strategy == kStratDfast ? (16 << 10) : (32 << 10)) : 0;
         if (hb > 0) {
             // what the level resolves to at the frame's size decides the form: the fast strategy keeps full 64 KiB blocks and
             // finds far matches through its table (candidates in front of the block are verified against global memory, up to
