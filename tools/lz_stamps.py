@@ -13,7 +13,7 @@ raw.ZSTDMI_debugReadSeqEncStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong),
 enames = ["repcodes", "histograms", "tables (lane 0)", "pack+flush (+batch load)", "state chains"]
 snames = ["other", "state chain", "fields+reps", "literals", "indep matches", "dependent matches"]
 hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
-names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense:marks-barrier wait", "dense:finish+rank", "sel:segment fns", "sel:barrier1", "sel:chain", "sel:marks"]
+names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense tile: select", "dense tile: finish+rank", "region: candidates (I)", "region: load pass", "region: parse", "region: parse barrier", "region: continuation+scan", "region: emit+literals"]
 n = 256 << 20
 for kind in ("zipf", "text"):
     host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), 8)[:n]
@@ -24,8 +24,8 @@ for kind in ("zipf", "text"):
     buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1); raw.ZSTDMI_debugReadHufStamps(buf, 1); raw.ZSTDMI_debugReadSeqEncStamps(buf, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     raw.ZSTDMI_debugReadLzStamps(buf, 1)
-    tot = sum(buf[i] for i in range(14)); chunks = n // 65536
-    print(kind, "lz wave-cycles/chunk/16", tot // chunks // 16, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(14)}, flush=True)
+    tot = sum(buf[i] for i in range(16)); chunks = n // 65536
+    print(kind, "lz wave-cycles/chunk/16", tot // chunks // 16, {names[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(16)}, flush=True)
     raw.ZSTDMI_debugReadHufStamps(buf, 1)
     tot = sum(buf[i] for i in range(8))
     print(kind, "huf_build cycles/chunk", tot // chunks, {hnames[i]: f"{100.0 * buf[i] / tot:.1f}%" for i in range(8)}, flush=True)

@@ -36,8 +36,11 @@ namespace zmi {
 // diagnostic build only (make STAMPS=1): per-phase shader-clock sums of thread 0 of every workgroup
 __device__ unsigned long long g_lzStamps[16];
 #define ZMI_STAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
+// (the region parse is a function of its own: it times itself from its entry and adds to the global sums directly)
+#define ZMI_DSTAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_lzStamps[i], now_ - dLast); dLast = now_; } } while (0)
 #else
 #define ZMI_STAMP(i) do { } while (0)
+#define ZMI_DSTAMP(i) do { } while (0)
 #endif
 
 constexpr u32 kHashLog  = 13;            // the reference's hashLog for level 1 at <= 128 KiB (U/Clevels.cs:488)
@@ -48,6 +51,9 @@ constexpr u32 kTileLog  = 12;
 constexpr u32 kGroups   = kTilePos / 64; // 64-position groups per tile
 constexpr u32 kLenCap   = 32;            // per-lane forward extension cap; capped matches are finished by wave 0
 constexpr u32 kInPad    = 64;
+constexpr u32 kDenseMin = 384;           // matches in a chunk's first tile from which the rest of the chunk goes to the region parse
+constexpr u32 kPassPos  = 30720;         // positions per pass of the region parse: their candidates (u16) fill the 64 KiB of the tables
+constexpr u32 kRegions  = kPassPos / 64; // 64-position regions per pass, one lane each
 // FAR mode (row f-1 for the fast strategy): the table also holds positions of the input IN FRONT of the block, up to kFarMax
 // bytes back inside the block's frame; table entries are (rel + 1) << 14 | tag14 with rel = kFarMax + block position
 constexpr u32 kFarMax   = (192u << 10) - 4096;
@@ -171,6 +177,259 @@ __device__ __forceinline__ u32 match_len_far(const LzLds& L, u32 p, const u8* __
     return l >= 4 ? l : 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Region parse (fast strategy, dense data).  The tile loop above computes a verified match at EVERY position and then selects
+// one position in eight; on dense data that verification and the selection machinery are most of its time.  Here the rest of
+// a chunk (tiles [fromTile, nTiles)) is done in two steps:
+//   I   per tile, as above: every position is hashed and inserted, but only the POSITION of its best-looking candidate (a
+//       period, else the same-tile first occurrence, else the latest earlier one — tags checked, bytes not) is kept: 2 bytes
+//       per position, through global memory (L2), because the tables still fill LDS;
+//   II  passes of 30 720 positions whose candidates now take the tables' place in LDS: the positions are cut into regions of
+//       64, ONE LANE PER REGION walks its region the way the reference's finder walks a block (U/ZstdFast.cs:130-260): look
+//       at the candidate, verify, extend backward over pending literals, take the match, jump behind it; only the positions it
+//       visits cost anything.  A match ends at its region's end; the next region continues it (same offset, through its
+//       leading literals) in a second, parallel step, so that a match is only cut where the next region had found something
+//       else.  Ranks, literal runs and coverage come from wave scans over the regions; every lane emits its own sequences.
+// Any parse is a valid parse: what this loses against the exact greedy orbit is a match start within the last three positions
+// of a region (found two or three bytes late by the next one).
+// ---------------------------------------------------------------------------------------------------------------------
+struct DenseLds {                        // laid over the tile arrays (tileLen .. jump), which the tile loop no longer needs
+    u64 keep[kRegions];                  // bit = byte is a literal (not covered by a match, not before the entry cursor)
+    u32 keepExcl[kRegions];              // literals of the pass before this region
+    u16 openOff[kRegions];               // offset of a last match that ends exactly at the region's end, 0 = none
+    u8  cont[kRegions];                  // leading bytes that continue the previous region's open match
+    u32 waveTot[3][16];                  // cross-wave scan: matches, kept literals, last end
+};
+
+__device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 fromTile, const u32 nTiles,
+                                           u16* __restrict__ candG, u32* const table, u32* const first,
+                                           Seq* __restrict__ seqOut, u8* __restrict__ litOut,
+                                           u32& cursor, u32& nbSeq, u32& litBase, bool& deferred, const u32 tid, const u32 lane, const u32 wave)
+{
+    static_assert(sizeof(DenseLds) <= sizeof(L.tileLen) + sizeof(L.tileOff) + sizeof(L.jump), "DenseLds must fit over tileLen .. jump");
+    DenseLds& D = *reinterpret_cast<DenseLds*>(&L.tileLen[0]);
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long dLast = __builtin_amdgcn_s_memtime();
+#endif
+    // ---------------- I: candidates of every position, tile by tile ----------------
+    for (u32 t = fromTile; t < nTiles; ++t) {
+        const u32 tileStart = t * kTilePos;
+        const u32 stamp = ((kChunkSize / kTilePos) - t - 1) << kTileLog;
+        u64 w[kPPT]; u32 h[kPPT], cnd[kPPT]; bool valid[kPPT];
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 q = j * kTile + tid, p = tileStart + q;
+            valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cnd[j] = 0;
+            if (valid[j]) {
+                w[j] = lds_load8(L.in, p);
+                h[j] = hash6p(w[j]);
+                cnd[j] = table[hidx(h[j])];
+                atomicMin(&first[hidx(h[j])], ((stamp + q) << 16) | htag(h[j]));
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 q = j * kTile + tid, p = tileStart + q;
+            u32 cp = 0;                                   // candidate position + 1
+            if (valid[j]) {
+                const u32 tag = htag(h[j]);
+                atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | tag);
+                const u32 lo = (u32)w[j], hi = (u32)(w[j] >> 32);
+                const bool i4 = lo == hi;
+                const bool i3 = __builtin_amdgcn_alignbyte(hi, lo, 3) == lo && ((hi ^ (hi >> 24)) & 0xFFu) == 0;
+                u32 per = 0;
+                if (i4 | i3) {                            // periods 1..4, as in the tile loop
+                    const u32 prev4 = lds_load4(L.in, p - 4);
+                    const bool i2 = i4 && ((lo ^ (lo >> 16)) & 0xFFFFu) == 0, i1 = i2 && ((lo ^ (lo >> 8)) & 0xFFu) == 0;
+                    if (i4 && prev4 == lo) per = 4;
+                    if (i3 && (prev4 >> 8) == (lo & 0xFFFFFFu)) per = 3;
+                    if (i2 && (prev4 >> 16) == (lo & 0xFFFFu)) per = 2;
+                    if (i1 && (prev4 >> 24) == (lo & 0xFFu)) per = 1;
+                }
+                if (per) cp = p - per + 1;
+                else {
+                    const u32 f = first[hidx(h[j])];
+                    const u32 fq = (f >> 16) - stamp;
+                    if (fq < q && (f & 0xFFFFu) == tag) cp = tileStart + fq + 1;
+                    else if (cnd[j] && (cnd[j] & 0xFFFFu) == tag) cp = cnd[j] >> 16;
+                }
+            }
+            if (p < n) candG[p] = (u16)cp;
+        }
+        __syncthreads();
+    }
+    ZMI_DSTAMP(10);
+    if (deferred) {                                       // (uniform) the bytes counted so far, out of LDS (see the tile loop)
+        for (u32 q16 = tid * 16; q16 < litBase; q16 += kTile * 16) {
+            const uint4 v = *reinterpret_cast<const uint4*>(L.in + q16);
+            u32u* o = (u32u*)(litOut + q16);
+            o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        }
+        deferred = false;
+    }
+    // ---------------- II: passes of kPassPos positions ----------------
+    u16* const C = reinterpret_cast<u16*>(L.tabMem);
+    for (u32 lo = fromTile * kTilePos; lo < n; lo += kPassPos) {
+        const u32 hi = lo + kPassPos < n ? lo + kPassPos : n;
+        const u32 nReg = (hi - lo + 63) >> 6;
+        for (u32 i = tid * 8; i < hi - lo; i += kTile * 8)           // candidates of the pass: global (L2) -> LDS, 16 bytes per lane
+            *reinterpret_cast<uint4*>(C + i) = *reinterpret_cast<const uint4*>(candG + lo + i);
+        __syncthreads();
+        ZMI_DSTAMP(11);
+        const u32 rs = lo + tid * 64, re = rs + 64 < hi ? rs + 64 : hi;
+        const bool mine = tid < nReg;
+        u64 sel = 0, cov = 0; u32 anchor = 0, lastOff = 0, firstOff = 0; bool selfFull = false;
+        if (mine) {
+            u32 p = rs > cursor ? rs : cursor;                       // positions before the entry cursor lie inside an earlier match
+            if (p > rs) cov = p - rs >= 64 ? ~0ull : ((1ull << (p - rs)) - 1);
+            anchor = p;
+            while (p < re) {
+                const u32 cp = C[p - lo];
+                if (!cp || p + 8 > n) { ++p; continue; }
+                u32 cpos = cp - 1;
+                u64 a1, a2, c1, c2;
+                lds_load16(L.in, p, a1, a2); lds_load16(L.in, cpos, c1, c2);
+                const u64 x1 = a1 ^ c1, x2 = a2 ^ c2;
+                u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
+                if (l == 16) {
+                    while (l < 64) {
+                        const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
+                        if (x) { l += ctz64(x) >> 3; break; }
+                        l += 8;
+                    }
+                }
+                const u32 room = (re < n ? re : n) - p;              // a match ends with its region (the next one continues it)
+                if (l > room) l = room;
+                if (l < 4) { ++p; continue; }
+                const u32 off = p - cpos;
+                while (p > anchor && cpos > 0 && L.in[p - 1] == L.in[cpos - 1]) { --p; --cpos; ++l; }     // ZstdFast.cs:242-247
+                C[p - lo] = (u16)off; C[p - lo + 1] = (u16)l;         // the record of a taken match: where its candidate and the next one were
+                if (!sel) { firstOff = off; selfFull = p == rs && l == 64; }
+                sel |= 1ull << (p - rs);
+                cov |= (l >= 64 ? ~0ull : ((1ull << l) - 1)) << (p - rs);
+                p += l; anchor = p; lastOff = off;
+            }
+            D.openOff[tid] = (sel && anchor == re && re == rs + 64) ? (u16)lastOff : (u16)0;
+        }
+        ZMI_DSTAMP(12);
+        __syncthreads();
+        ZMI_DSTAMP(13);
+        // ---- continuation: the previous region's open match runs on through this region's leading literals; a region whose
+        // own parse is ONE match over all its 64 bytes with the offset of the open match in front of it is a link of that match
+        // (a long match or run comes out of the region parse as a chain of such regions: one sequence, owned by the chain's head) ----
+        u32 cont = 0;
+        if (mine && tid > 0 && rs >= cursor) {
+            const u32 o = D.openOff[tid - 1];
+            if (o) {
+                if (selfFull && firstOff == o) { cont = 64; sel = 0; cov = ~0ull; }
+                else {
+                    const u32 m1 = sel ? rs + ctz64(sel) : (re < n ? re : n);      // up to this region's first match
+                    u32 k = 0; bool diff = false;
+                    while (rs + k + 8 <= m1) {
+                        const u64 x = lds_load8(L.in, rs + k) ^ lds_load8(L.in, rs + k - o);
+                        if (x) { k += ctz64(x) >> 3; diff = true; break; }
+                        k += 8;
+                    }
+                    if (!diff) while (rs + k < m1 && L.in[rs + k] == L.in[rs + k - o]) ++k;
+                    cont = k;
+                    // the region's first match starts right where the continuation arrives, with the same offset: it IS the
+                    // continuation (found again by its own candidate): one sequence instead of two
+                    if (sel && rs + k == m1 && (u32)C[m1 - lo] == o) { cont += C[m1 - lo + 1]; sel &= sel - 1; }
+                    if (cont) cov |= cont >= 64 ? ~0ull : ((1ull << cont) - 1);
+                }
+            }
+        }
+        if (mine) D.cont[tid] = (u8)cont;
+        __syncthreads();
+        // ---- what every region contributes: sequences, literals kept, end of its last match (with what continues it) ----
+        u32 ext = 0;
+        if (mine && sel && D.openOff[tid]) {
+            for (u32 e = tid + 1; e < nReg; ++e) { const u32 ce = D.cont[e]; ext += ce; if (ce < 64) break; }
+        }
+        const u32 myEnd = (mine && sel) ? anchor + ext : 0u;
+        const u32 validBits = mine ? re - rs : 0u;
+        const u64 keep = mine ? ~cov & (validBits >= 64 ? ~0ull : ((1ull << validBits) - 1)) : 0ull;
+        const u32 nMatch = popc64(sel), nKeep = popc64(keep);
+        const u32 inclM = wave_scan_incl(nMatch), inclK = wave_scan_incl(nKeep);
+        u32 inclE = myEnd;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const u32 tE = __shfl_up(inclE, d); if ((int)lane >= d) inclE = tE > inclE ? tE : inclE; }
+        u32 prevEnd = __shfl_up(inclE, 1); if (lane == 0) prevEnd = 0;
+        if (lane == 63) { D.waveTot[0][wave] = inclM; D.waveTot[1][wave] = inclK; D.waveTot[2][wave] = inclE; }
+        __syncthreads();
+        u32 baseM = 0, baseK = 0, baseE = cursor, totM = 0, totK = 0, totE = cursor;
+#pragma unroll
+        for (u32 k2 = 0; k2 < 16; ++k2) {
+            const u32 m = D.waveTot[0][k2], kk = D.waveTot[1][k2], e = D.waveTot[2][k2];
+            if (k2 < wave) { baseM += m; baseK += kk; baseE = e > baseE ? e : baseE; }
+            totM += m; totK += kk; totE = e > totE ? e : totE;
+        }
+        ZMI_DSTAMP(14);
+        if (mine) { D.keep[tid] = keep; D.keepExcl[tid] = baseK + inclK - nKeep; }
+        // ---- sequences: every region's lane emits its own, in order ----
+        if (mine && sel) {
+            prevEnd = prevEnd > baseE ? prevEnd : baseE;                      // end of the last match before this region
+            u32 r = nbSeq + baseM + inclM - nMatch;
+            u64 b = sel;
+            while (b) {
+                const u32 bit = ctz64(b); b &= b - 1;
+                const u32 sPos = rs + bit;
+                const u32 off = C[sPos - lo]; u32 l = C[sPos - lo + 1];
+                if (!b) l += ext;
+                Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(sPos - prevEnd); sq.mlBase = (u16)(l - 3);
+                seqOut[r++] = sq;
+                prevEnd = sPos + l;
+            }
+        }
+        __syncthreads();
+        // ---- literals: compacted in LDS first (the candidates' place: they are spent), then written out in whole 16-byte pieces:
+        // on dense data the runs between matches are three or four bytes long, and a byte store to global memory each is what
+        // this step would otherwise consist of.  32 positions per thread, two threads per region ----
+        {
+            u8* const S = reinterpret_cast<u8*>(L.tabMem);
+            const u32 g = tid >> 1, half = tid & 1u;
+            if (g < nReg) {
+                const u64 kg = D.keep[g];
+                u32 k32 = half ? (u32)(kg >> 32) : (u32)kg;
+                if (k32) {
+                    u8* o = S + D.keepExcl[g] + (half ? popc64(kg & 0xFFFFFFFFull) : 0u);
+                    const u32 pos0 = lo + g * 64 + half * 32;
+                    if (k32 == 0xFFFFFFFFu) {             // nothing matched here: 32 bytes straight through
+                        const uint4 v0 = *reinterpret_cast<const uint4*>(L.in + pos0), v1 = *reinterpret_cast<const uint4*>(L.in + pos0 + 16);
+                        u32u* o4 = (u32u*)o; o4[0] = v0.x; o4[1] = v0.y; o4[2] = v0.z; o4[3] = v0.w; o4[4] = v1.x; o4[5] = v1.y; o4[6] = v1.z; o4[7] = v1.w;
+                    } else {
+                        while (k32) {                     // run by run: a run of set bits is a run of literals
+                            const u32 b0 = (u32)__builtin_ctz(k32);
+                            const u32 inv = ~(k32 >> b0);
+                            const u32 len = inv ? (u32)__builtin_ctz(inv) : 32u - b0;
+                            for (u32 i = 0; i < len; ++i) o[i] = L.in[pos0 + b0 + i];
+                            o += len;
+                            k32 = (len + b0 >= 32) ? 0u : (k32 & (0xFFFFFFFFu << (b0 + len)));
+                        }
+                    }
+                }
+            }
+            __syncthreads();
+            u8* const dst = litOut + litBase;
+            // (litBase is whatever earlier tiles left: the head brings the destination to 16-byte alignment)
+            u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15); if (head > totK) head = totK;
+            if (tid < head) dst[tid] = S[tid];
+            const u32 body = (totK - head) >> 4;
+            for (u32 i = tid; i < body; i += kTile) {
+                uint4 v; const u8* sp = S + head + 16 * i;
+                v.x = *(const u32u*)sp; v.y = *(const u32u*)(sp + 4); v.z = *(const u32u*)(sp + 8); v.w = *(const u32u*)(sp + 12);
+                *reinterpret_cast<uint4*>(dst + head + 16 * i) = v;
+            }
+            const u32 done = head + (body << 4);
+            if (tid < totK - done) dst[done + tid] = S[done + tid];
+        }
+        __syncthreads();
+        ZMI_DSTAMP(15);
+        cursor = totE; nbSeq += totM; litBase += totK;
+    }
+}
+
 // MODE 0 = fast strategy (one 6-byte hash; levels 1-2 and the negative levels); 1 = doubleFast strategy (8-byte + SHORT-byte
 // hashes, four candidates per position; levels 3-4: the place of U/ZstdDoubleFast.cs:51-247); 2 = greedy and above (the dual
 // candidates + one-step lazy deferral; levels >= 5: the place of U/ZstdLazy.cs:1743-2032).  The host maps strategy -> MODE.
@@ -181,7 +440,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u16* __restrict__ candAll)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -335,6 +594,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // Where the previous tile found next to nothing, this tile probes every 2nd or 4th position only — the reference's own
     // acceleration (ZSTD_fast's step = 1 + ((ip - anchor) >> kSearchStrength), U/ZstdFast.cs:130-136).  A match that starts
     // between probed positions is still picked up one or two bytes later and grown backward at emission.
+    u32 denseFrom = 0;                   // first tile of the part of the chunk that the region parse takes (0 = none)
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     u32 prevStride = 0;                  // the previous iteration's stride
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
@@ -600,9 +860,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (lane == 0) *segExit0 = z;
                 }
             }
-            ZMI_STAMP(10);
+            ZMI_STAMP(8);
             __syncthreads();
-            ZMI_STAMP(11);
+            ZMI_STAMP(8);
             if (wave >= w0) {                                                 // (uniform) earlier waves lie before the cursor: nothing selected
                 u32 ent = e0, kStart = k0;
                 if (wave > w0) {
@@ -613,7 +873,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #pragma unroll
                     for (u32 k = 1; k < 15; ++k) if (k > w0 && k < wave) ent = read_lane(fv[k], ent);
                 }
-                ZMI_STAMP(12);
+                ZMI_STAMP(8);
 #pragma unroll
                 for (u32 k = 0; k < 4; ++k) {
                     if (k < kStart) continue;                                 // uniform
@@ -625,7 +885,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     if (lane == 0) L.selMask[wave * 4 + k] = mark;
                 }
             }
-            ZMI_STAMP(13);
+            ZMI_STAMP(8);
             __syncthreads();
             ZMI_STAMP(8);
             if (wave == 0) {
@@ -808,6 +1068,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         }
         t += nSub;
         ZMI_STAMP(7);
+        // a chunk whose first tile is dense in matches (text, source code, structured data) hands the rest of itself to the
+        // region parse below: the tile loop verifies every position to keep one in eight
+        if (MODE == 0 && !DICT && !FAR && candAll && it == 0 && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > 2) { denseFrom = t; break; }
+    }
+    if (MODE == 0 && !DICT && !FAR && denseFrom) {
+        dense_rest(L, n, denseFrom, nTiles, candAll + (u64)c * kChunkSize, table, first, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
     }
 #ifdef ZMI_LZ_STAMPS
     if ((tid & 63u) == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
@@ -837,7 +1103,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, hipStream_t stream)
 {
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
@@ -846,7 +1112,7 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -855,24 +1121,24 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // rounded up to whole 4 KiB tiles.  frameBlocks > 0: cross-chunk history instead (no dictionary): `frameBlocks` chunks of chunkBytes
 // form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, hipStream_t stream)
 {
     if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
-        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, stream);
+        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, stream);
         return;
     }
     if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, nullptr, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, nullptr, stream); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, nullptr, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, nullptr, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, nullptr, stream); break;
     }
 }
 

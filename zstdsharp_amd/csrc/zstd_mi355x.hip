@@ -18,7 +18,7 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
@@ -119,7 +119,7 @@ struct ZSTD_CCtx_s {
     int windowLog = 0, hashLog = 0, chainLog = 0, searchLog = 0, minMatch = 0, targetLength = 0, strategy = 0;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf seqs, lits, meta, tables, slots, offsets, total, stageSrc, stageDst;
+    DevBuf seqs, lits, meta, tables, slots, offsets, total, cand, stageSrc, stageDst;
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
     const u8* lastSrc = nullptr; u32 lastChunkBytes = 0;     // its source (debug hook: chunks without sequences keep their literals there)
     u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
@@ -241,6 +241,8 @@ static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
            c->slots.ensure((size_t)nChunks * kSlotStride + 64) && c->offsets.ensure((size_t)nChunks * sizeof(u64)) &&
            c->total.ensure(64);
 }
+// the region parse of the fast strategy keeps one candidate position (u16) per input byte between its two steps (lz_fast.hip)
+static bool cctx_cand_workspace(ZSTD_CCtx* c, u32 nChunks) { return c->cand.ensure((size_t)nChunks * kChunkSize * sizeof(u16) + 256); }
 
 // upload a newly loaded dictionary; a formatted one is first validated on the device (ZSTD_loadCEntropy's checks are those of
 // ZSTD_loadDEntropy plus the symbol-coverage rules that only matter to an encoder reusing the tables) -> dictionary_corrupted
@@ -320,6 +322,8 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
     u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
     if (frameBlocks && passChunks < totalChunks) { passChunks -= passChunks % frameBlocks; if (!passChunks) passChunks = frameBlocks; }     // frames never straddle passes
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
+    const bool regionParse = rs.finder == 0 && prefixLen == 0 && frameBlocks == 0 && rs.minStrideLog == 0;
+    if (regionParse && !cctx_cand_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy;      // ZSTD_selectEncodingType's < lazy heuristic is the one seq_encode holds (U/ZstdCompressSequences.cs:400-469): levels whose strategy is lazy or above get greedy's constants
     size_t produced = 0;
     bool first = true;
@@ -330,7 +334,7 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, s);      c->timer.mark("lz_fast", s);
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, s);      c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s);        c->timer.mark("huf_build", s);
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
@@ -364,7 +368,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
     if (c->deviceOk) {
         (void)hipSetDevice(c->device);
         if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
-        c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release();
+        c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release(); c->cand.release();
         c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release(); c->dictFullDev.release(); c->dictInfoDev.release();
         c->timer.destroy();
         if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
