@@ -196,8 +196,12 @@ __device__ __forceinline__ u32 match_len_far(const LzLds& L, u32 p, const u8* __
 struct DenseLds {                        // laid over the tile arrays (tileLen .. jump), which the tile loop no longer needs
     u64 keep[kRegions];                  // bit = byte is a literal (not covered by a match, not before the entry cursor)
     u32 keepExcl[kRegions];              // literals of the pass before this region
-    u16 openOff[kRegions];               // offset of a last match that ends exactly at the region's end, 0 = none
-    u8  cont[kRegions];                  // leading bytes that continue the previous region's open match
+    u64 covHi[kRegions];                 // bytes of the NEXT region that this lane's matches cover (its stretch runs up to espec)
+    u32 espec[kRegions];                 // where the speculative parse leaves the region
+    u32 lastEnd[kRegions];               // end of the lane's last match, 0 = no match
+    u16 lastOff[kRegions];               // ... and its offset
+    u16 cont[kRegions];                  // length of a first match that continues the match before it (absorbed by that one)
+    u8  more[kRegions];                  // the lane has matches of its own besides
     u32 waveTot[3][16];                  // cross-wave scan: matches, kept literals, last end
 };
 
@@ -273,113 +277,175 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
     for (u32 lo = fromTile * kTilePos; lo < n; lo += kPassPos) {
         const u32 hi = lo + kPassPos < n ? lo + kPassPos : n;
         const u32 nReg = (hi - lo + 63) >> 6;
-        for (u32 i = tid * 8; i < hi - lo; i += kTile * 8)           // candidates of the pass: global (L2) -> LDS, 16 bytes per lane
+        for (u32 i = tid * 8; i < hi - lo + 64; i += kTile * 8)      // candidates of the pass (+ one region: a lane's stretch may reach that far): global (L2) -> LDS, 16 bytes per lane
             *reinterpret_cast<uint4*>(C + i) = *reinterpret_cast<const uint4*>(candG + lo + i);
         __syncthreads();
         ZMI_DSTAMP(11);
         const u32 rs = lo + tid * 64, re = rs + 64 < hi ? rs + 64 : hi;
         const bool mine = tid < nReg;
-        u64 sel = 0, cov = 0; u32 anchor = 0, lastOff = 0, firstOff = 0; bool selfFull = false;
-        if (mine) {
-            u32 p = rs > cursor ? rs : cursor;                       // positions before the entry cursor lie inside an earlier match
-            if (p > rs) cov = p - rs >= 64 ? ~0ull : ((1ull << (p - rs)) - 1);
-            anchor = p;
-            while (p < re) {
-                const u32 cp = C[p - lo];
-                if (!cp || p + 8 > n) { ++p; continue; }
-                u32 cpos = cp - 1;
-                u64 a1, a2, c1, c2;
-                lds_load16(L.in, p, a1, a2); lds_load16(L.in, cpos, c1, c2);
-                const u64 x1 = a1 ^ c1, x2 = a2 ^ c2;
-                u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
-                if (l == 16) {
-                    while (l < 64) {
-                        const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
-                        if (x) { l += ctz64(x) >> 3; break; }
-                        l += 8;
-                    }
+        // the candidate at position p verified against the input: match length (0 = none), at most 64 and never past the data
+        auto verify = [&](u32 p, u32 cpos) -> u32 {
+            u64 a1, a2, c1, c2;
+            lds_load16(L.in, p, a1, a2); lds_load16(L.in, cpos, c1, c2);
+            const u64 x1 = a1 ^ c1, x2 = a2 ^ c2;
+            u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
+            if (l == 16) {
+                while (l < 64) {
+                    const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
+                    if (x) { l += ctz64(x) >> 3; break; }
+                    l += 8;
                 }
-                const u32 room = (re < n ? re : n) - p;              // a match ends with its region (the next one continues it)
-                if (l > room) l = room;
-                if (l < 4) { ++p; continue; }
-                const u32 off = p - cpos;
-                while (p > anchor && cpos > 0 && L.in[p - 1] == L.in[cpos - 1]) { --p; --cpos; ++l; }     // ZstdFast.cs:242-247
-                C[p - lo] = (u16)off; C[p - lo + 1] = (u16)l;         // the record of a taken match: where its candidate and the next one were
-                if (!sel) { firstOff = off; selfFull = p == rs && l == 64; }
-                sel |= 1ull << (p - rs);
-                cov |= (l >= 64 ? ~0ull : ((1ull << l) - 1)) << (p - rs);
-                p += l; anchor = p; lastOff = off;
+                if (l > 64) l = 64;
             }
-            D.openOff[tid] = (sel && anchor == re && re == rs + 64) ? (u16)lastOff : (u16)0;
+            if (l > n - p) l = n - p;
+            return l >= 4 ? l : 0u;
+        };
+        // ---- step 1, speculative: where does the parse LEAVE this region?  The lane starts kWarm positions in front of its region
+        // (the first region of a pass at the cursor it was handed): a greedy parse forgets where it started within a few matches,
+        // so it usually leaves the region exactly where the parse that comes through the regions before it will.  Nothing is written ----
+        constexpr u32 kWarm = 32;
+        const bool lastReg = tid + 1 == nReg;
+        u32 eSpec = 0;
+        if (mine) {
+            u32 p = tid == 0 ? rs : rs - kWarm;
+            if (p < cursor) p = cursor;
+            while (p < re) {
+                // four candidates per LDS round trip: positions without one (literals) cost no round trip of their own
+                const u64 c4 = *reinterpret_cast<const u64u*>(C + (p - lo));
+                if (!c4) { p += 4; continue; }
+                const u32 skip = ctz64(c4) >> 4;
+                p += skip;
+                if (p >= re) break;
+                const u32 cp = (u32)(c4 >> (16 * skip)) & 0xFFFFu;
+                const u32 l = (p + 8 <= n) ? verify(p, cp - 1) : 0u;
+                p += l ? l : 1u;
+            }
+            if (p < re) p = re;
+            eSpec = p;
+            D.espec[tid] = eSpec;
         }
         ZMI_DSTAMP(12);
         __syncthreads();
         ZMI_DSTAMP(13);
-        // ---- continuation: the previous region's open match runs on through this region's leading literals; a region whose
-        // own parse is ONE match over all its 64 bytes with the offset of the open match in front of it is a link of that match
-        // (a long match or run comes out of the region parse as a chain of such regions: one sequence, owned by the chain's head) ----
-        u32 cont = 0;
-        if (mine && tid > 0 && rs >= cursor) {
-            const u32 o = D.openOff[tid - 1];
-            if (o) {
-                if (selfFull && firstOff == o) { cont = 64; sel = 0; cov = ~0ull; }
-                else {
-                    const u32 m1 = sel ? rs + ctz64(sel) : (re < n ? re : n);      // up to this region's first match
-                    u32 k = 0; bool diff = false;
-                    while (rs + k + 8 <= m1) {
-                        const u64 x = lds_load8(L.in, rs + k) ^ lds_load8(L.in, rs + k - o);
-                        if (x) { k += ctz64(x) >> 3; diff = true; break; }
-                        k += 8;
-                    }
-                    if (!diff) while (rs + k < m1 && L.in[rs + k] == L.in[rs + k - o]) ++k;
-                    cont = k;
-                    // the region's first match starts right where the continuation arrives, with the same offset: it IS the
-                    // continuation (found again by its own candidate): one sequence instead of two
-                    if (sel && rs + k == m1 && (u32)C[m1 - lo] == o) { cont += C[m1 - lo + 1]; sel &= sel - 1; }
-                    if (cont) cov |= cont >= 64 ? ~0ull : ((1ull << cont) - 1);
+        // ---- step 2, for real: from where the region before this one is left by ITS speculation to exactly where this region's
+        // own speculation left it (there the next lane starts: no byte is parsed twice, none is skipped; the pass's last region
+        // simply runs to its end).  A match is cut where the lane's stretch ends.  A taken match is recorded where its candidate
+        // was (offset) and one entry further (length); a match that starts where the one before it ended, with the same offset,
+        // is that match going on (the verification stops at 64 bytes) ----
+        u64 selLo = 0, selHi = 0, covLo = 0, covHi = 0;     // Lo: positions of this region; Hi: the stretch beyond it, up to eSpec
+        u32 lastEnd = 0, lastOff = 0, lastStart = 0, firstOff = 0, firstLen = 0, firstStart = 0;
+        if (mine) {
+            u32 p = tid == 0 ? rs : D.espec[tid - 1];
+            if (p < cursor) p = cursor;
+            const u32 bound = lastReg ? re : eSpec;
+            u32 anchor = p;
+            while (p < bound) {
+                const u64 c4 = *reinterpret_cast<const u64u*>(C + (p - lo));
+                if (!c4) { p += 4; continue; }
+                const u32 skip = ctz64(c4) >> 4;
+                p += skip;
+                if (p >= bound) break;
+                const u32 cp = (u32)(c4 >> (16 * skip)) & 0xFFFFu;
+                if (p + 8 > n) { ++p; continue; }
+                u32 cpos = cp - 1;
+                u32 l = verify(p, cpos);
+                if (!lastReg && p + l > eSpec) l = eSpec - p;
+                if (l < 4) { ++p; continue; }
+                const u32 off = p - cpos;
+                while (p > anchor && cpos > 0 && L.in[p - 1] == L.in[cpos - 1]) { --p; --cpos; ++l; }     // ZstdFast.cs:242-247
+                const u32 q = p - rs;                                    // 0 .. 126
+                {   // bytes [q, q + l) of the lane's stretch (a backward extension can make a match longer than the 64 verified bytes)
+                    const u32 e = q + l;
+                    if (q < 64) covLo |= (~0ull << q) & (e >= 64 ? ~0ull : ((1ull << e) - 1));
+                    if (e > 64) { const u32 hs = q > 64 ? q - 64 : 0u, he = e - 64; covHi |= (~0ull << hs) & (he >= 64 ? ~0ull : ((1ull << he) - 1)); }
                 }
+#ifdef ZMI_DBG_NOMERGE
+                if (false) {
+#else
+                if (lastEnd == p && lastOff == off && (selLo | selHi)) {
+#endif
+                    C[lastStart - lo + 1] = (u16)(C[lastStart - lo + 1] + l);      // the match before it, going on
+                    if (lastStart == firstStart) firstLen += l;
+                } else {
+                    C[p - lo] = (u16)off; C[p - lo + 1] = (u16)l;
+                    if (!(selLo | selHi)) { firstOff = off; firstLen = l; firstStart = p; }
+                    if (q < 64) selLo |= 1ull << q; else selHi |= 1ull << (q - 64);
+                    lastStart = p;
+                }
+                p += l; anchor = p; lastOff = off; lastEnd = p;
             }
+            D.lastEnd[tid] = lastEnd; D.lastOff[tid] = (u16)lastOff; D.covHi[tid] = covHi;
         }
-        if (mine) D.cont[tid] = (u8)cont;
-        __syncthreads();
-        // ---- what every region contributes: sequences, literals kept, end of its last match (with what continues it) ----
-        u32 ext = 0;
-        if (mine && sel && D.openOff[tid]) {
-            for (u32 e = tid + 1; e < nReg; ++e) { const u32 ce = D.cont[e]; ext += ce; if (ce < 64) break; }
-        }
-        const u32 myEnd = (mine && sel) ? anchor + ext : 0u;
-        const u32 validBits = mine ? re - rs : 0u;
-        const u64 keep = mine ? ~cov & (validBits >= 64 ? ~0ull : ((1ull << validBits) - 1)) : 0ull;
-        const u32 nMatch = popc64(sel), nKeep = popc64(keep);
-        const u32 inclM = wave_scan_incl(nMatch), inclK = wave_scan_incl(nKeep);
-        u32 inclE = myEnd;
+        ZMI_DSTAMP(12);
+        // ---- ends of the matches so far, over the regions (prefix maximum): where the literals in front of a region's first match begin ----
+        u32 inclE = lastEnd;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 tE = __shfl_up(inclE, d); if ((int)lane >= d) inclE = tE > inclE ? tE : inclE; }
         u32 prevEnd = __shfl_up(inclE, 1); if (lane == 0) prevEnd = 0;
-        if (lane == 63) { D.waveTot[0][wave] = inclM; D.waveTot[1][wave] = inclK; D.waveTot[2][wave] = inclE; }
+        if (lane == 63) D.waveTot[2][wave] = inclE;
         __syncthreads();
-        u32 baseM = 0, baseK = 0, baseE = cursor, totM = 0, totK = 0, totE = cursor;
+        ZMI_DSTAMP(13);
+        u32 baseE = cursor, totE = cursor;
+#pragma unroll
+        for (u32 k2 = 0; k2 < 16; ++k2) { const u32 e = D.waveTot[2][k2]; if (k2 < wave) baseE = e > baseE ? e : baseE; totE = e > totE ? e : totE; }
+        prevEnd = prevEnd > baseE ? prevEnd : baseE;                          // end of the last match that starts before this lane's stretch
+        // ---- links: a lane's first match that starts exactly where the match before it ends, with the same offset, is that
+        // match going on (a long match or a run comes out of the lanes as a chain of pieces): the chain's head owns it ----
+        u32 absorbed = 0;
+        if (mine) {
+            if (tid > 0) covLo |= D.covHi[tid - 1];                            // what the lane before this one did beyond its region
+            if (cursor > rs) covLo |= cursor - rs >= 64 ? ~0ull : ((1ull << (cursor - rs)) - 1);     // a match from before the pass
+#ifdef ZMI_DBG_NOLINK
+            if (false) {
+#else
+            if ((selLo | selHi) && tid > 0 && firstStart == D.lastEnd[tid - 1] && firstOff == (u32)D.lastOff[tid - 1]) {
+#endif
+                absorbed = firstLen;
+                if (selLo) selLo &= selLo - 1; else selHi &= selHi - 1;
+            }
+            D.cont[tid] = (u16)absorbed; D.more[tid] = (selLo | selHi) ? (u8)1 : (u8)0;
+        }
+        __syncthreads();
+        // ---- what every lane contributes: sequences; what every region holds: literals ----
+        u32 ext = 0;
+        if (mine && (selLo | selHi)) {
+            for (u32 e = tid + 1; e < nReg; ++e) { const u32 ce = D.cont[e]; if (!ce) break; ext += ce; if (D.more[e]) break; }
+        }
+        const u32 validBits = mine ? re - rs : 0u;
+        const u64 keep = mine ? ~covLo & (validBits >= 64 ? ~0ull : ((1ull << validBits) - 1)) : 0ull;
+        const u32 nMatch = popc64(selLo) + popc64(selHi), nKeep = popc64(keep);
+        const u32 inclM = wave_scan_incl(nMatch), inclK = wave_scan_incl(nKeep);
+        if (lane == 63) { D.waveTot[0][wave] = inclM; D.waveTot[1][wave] = inclK; }
+        __syncthreads();
+        u32 baseM = 0, baseK = 0, totM = 0, totK = 0;
 #pragma unroll
         for (u32 k2 = 0; k2 < 16; ++k2) {
-            const u32 m = D.waveTot[0][k2], kk = D.waveTot[1][k2], e = D.waveTot[2][k2];
-            if (k2 < wave) { baseM += m; baseK += kk; baseE = e > baseE ? e : baseE; }
-            totM += m; totK += kk; totE = e > totE ? e : totE;
+            const u32 m = D.waveTot[0][k2], kk = D.waveTot[1][k2];
+            if (k2 < wave) { baseM += m; baseK += kk; }
+            totM += m; totK += kk;
         }
         ZMI_DSTAMP(14);
         if (mine) { D.keep[tid] = keep; D.keepExcl[tid] = baseK + inclK - nKeep; }
-        // ---- sequences: every region's lane emits its own, in order ----
-        if (mine && sel) {
-            prevEnd = prevEnd > baseE ? prevEnd : baseE;                      // end of the last match before this region
+#ifdef ZMI_DBG_KEEP
+        if (mine) { u64* dbg = reinterpret_cast<u64*>(candG + lo); dbg[tid * 4] = keep; dbg[tid * 4 + 1] = selLo; dbg[tid * 4 + 2] = selHi; dbg[tid * 4 + 3] = ((u64)eSpec << 32) | lastEnd; }
+#endif
+        // ---- sequences: every lane emits its own, in order ----
+        if (mine && nMatch) {
             u32 r = nbSeq + baseM + inclM - nMatch;
-            u64 b = sel;
-            while (b) {
-                const u32 bit = ctz64(b); b &= b - 1;
-                const u32 sPos = rs + bit;
-                const u32 off = C[sPos - lo]; u32 l = C[sPos - lo + 1];
-                if (!b) l += ext;
-                Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(sPos - prevEnd); sq.mlBase = (u16)(l - 3);
-                seqOut[r++] = sq;
-                prevEnd = sPos + l;
+            u32 pe = prevEnd;
+            if (absorbed) pe = firstStart + firstLen;                             // (the absorbed piece is the head's; literals count from its end)
+#pragma unroll 1
+            for (u32 hw = 0; hw < 2; ++hw) {
+                u64 b = hw ? selHi : selLo;
+                while (b) {
+                    const u32 bit = ctz64(b); b &= b - 1;
+                    const u32 sPos = rs + 64 * hw + bit;
+                    const u32 off = C[sPos - lo]; u32 l = C[sPos - lo + 1];
+                    if (!b && (hw || !selHi)) l += ext;                           // the lane's last match: what the lanes after it add
+                    Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(sPos - pe); sq.mlBase = (u16)(l - 3);
+                    seqOut[r++] = sq;
+                    pe = sPos + l;
+                }
             }
         }
         __syncthreads();
