@@ -13,7 +13,7 @@ raw.ZSTDMI_debugReadSeqEncStamps.argtypes = [ctypes.POINTER(ctypes.c_ulonglong),
 enames = ["repcodes", "histograms", "tables (lane 0)", "pack+flush (+batch load)", "state chains"]
 snames = ["other", "state chain", "fields+reps", "literals", "indep matches", "dependent matches"]
 hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
-names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense tile: select", "dense tile: finish+rank", "region: candidates (I)", "region: load pass", "region: parse", "region: parse barrier", "region: continuation+scan", "region: emit+literals"]
+names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense tile: select", "dense tile: finish+rank", "region: candidates (I)", "region: load pass", "region: speculative parse", "region: real parse", "region: links+scans", "region: emit+literals"]
 n = 256 << 20
 for kind in ("zipf", "text"):
     host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), 8)[:n]

@@ -37,7 +37,7 @@ namespace zmi {
 __device__ unsigned long long g_lzStamps[16];
 #define ZMI_STAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
 // (the region parse is a function of its own: it times itself from its entry and adds to the global sums directly)
-#define ZMI_DSTAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); atomicAdd(&g_lzStamps[i], now_ - dLast); dLast = now_; } } while (0)
+#define ZMI_DSTAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dAcc[(i) - 10] += now_ - dLast; dLast = now_; } } while (0)
 #else
 #define ZMI_STAMP(i) do { } while (0)
 #define ZMI_DSTAMP(i) do { } while (0)
@@ -177,6 +177,10 @@ __device__ __forceinline__ u32 match_len_far(const LzLds& L, u32 p, const u8* __
     return l >= 4 ? l : 0;
 }
 
+// workgroup barrier that orders LDS only: __syncthreads() also waits until every global store of the wave has been acknowledged
+// (vmcnt), which the region parse does not need where it only writes results out
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Region parse (fast strategy, dense data).  The tile loop above computes a verified match at EVERY position and then selects
 // one position in eight; on dense data that verification and the selection machinery are most of its time.  Here the rest of
@@ -213,7 +217,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
     static_assert(sizeof(DenseLds) <= sizeof(L.tileLen) + sizeof(L.tileOff) + sizeof(L.jump), "DenseLds must fit over tileLen .. jump");
     DenseLds& D = *reinterpret_cast<DenseLds*>(&L.tileLen[0]);
 #ifdef ZMI_LZ_STAMPS
-    unsigned long long dLast = __builtin_amdgcn_s_memtime();
+    unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     // ---------------- I: candidates of every position, tile by tile ----------------
     for (u32 t = fromTile; t < nTiles; ++t) {
@@ -231,7 +235,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                 atomicMin(&first[hidx(h[j])], ((stamp + q) << 16) | htag(h[j]));
             }
         }
-        __syncthreads();
+        lds_barrier();
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 q = j * kTile + tid, p = tileStart + q;
@@ -261,8 +265,9 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
             }
             if (p < n) candG[p] = (u16)cp;
         }
-        __syncthreads();
+        lds_barrier();                                    // (the tables; the candidates only have to have arrived before step II reads them)
     }
+    __syncthreads();
     ZMI_DSTAMP(10);
     if (deferred) {                                       // (uniform) the bytes counted so far, out of LDS (see the tile loop)
         for (u32 q16 = tid * 16; q16 < litBase; q16 += kTile * 16) {
@@ -277,9 +282,16 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
     for (u32 lo = fromTile * kTilePos; lo < n; lo += kPassPos) {
         const u32 hi = lo + kPassPos < n ? lo + kPassPos : n;
         const u32 nReg = (hi - lo + 63) >> 6;
-        for (u32 i = tid * 8; i < hi - lo + 64; i += kTile * 8)      // candidates of the pass (+ one region: a lane's stretch may reach that far): global (L2) -> LDS, 16 bytes per lane
-            *reinterpret_cast<uint4*>(C + i) = *reinterpret_cast<const uint4*>(candG + lo + i);
-        __syncthreads();
+        {   // candidates of the pass (+ one region: a lane's stretch may reach that far): global (L2) -> LDS, 16 bytes per lane,
+            // the four loads of a thread in flight together
+            const u32 cnt = hi - lo + 64;
+            uint4 v[4];
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) { const u32 i = (tid + k * kTile) * 8; v[k] = *reinterpret_cast<const uint4*>(candG + lo + (i < cnt ? i : 0)); }
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) { const u32 i = (tid + k * kTile) * 8; if (i < cnt) *reinterpret_cast<uint4*>(C + i) = v[k]; }
+        }
+        lds_barrier();
         ZMI_DSTAMP(11);
         const u32 rs = lo + tid * 64, re = rs + 64 < hi ? rs + 64 : hi;
         const bool mine = tid < nReg;
@@ -325,8 +337,8 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
             D.espec[tid] = eSpec;
         }
         ZMI_DSTAMP(12);
-        __syncthreads();
-        ZMI_DSTAMP(13);
+        lds_barrier();
+        ZMI_DSTAMP(12);
         // ---- step 2, for real: from where the region before this one is left by ITS speculation to exactly where this region's
         // own speculation left it (there the next lane starts: no byte is parsed twice, none is skipped; the pass's last region
         // simply runs to its end).  A match is cut where the lane's stretch ends.  A taken match is recorded where its candidate
@@ -359,11 +371,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                     if (q < 64) covLo |= (~0ull << q) & (e >= 64 ? ~0ull : ((1ull << e) - 1));
                     if (e > 64) { const u32 hs = q > 64 ? q - 64 : 0u, he = e - 64; covHi |= (~0ull << hs) & (he >= 64 ? ~0ull : ((1ull << he) - 1)); }
                 }
-#ifdef ZMI_DBG_NOMERGE
-                if (false) {
-#else
                 if (lastEnd == p && lastOff == off && (selLo | selHi)) {
-#endif
                     C[lastStart - lo + 1] = (u16)(C[lastStart - lo + 1] + l);      // the match before it, going on
                     if (lastStart == firstStart) firstLen += l;
                 } else {
@@ -376,14 +384,14 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
             }
             D.lastEnd[tid] = lastEnd; D.lastOff[tid] = (u16)lastOff; D.covHi[tid] = covHi;
         }
-        ZMI_DSTAMP(12);
+        ZMI_DSTAMP(13);
         // ---- ends of the matches so far, over the regions (prefix maximum): where the literals in front of a region's first match begin ----
         u32 inclE = lastEnd;
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) { const u32 tE = __shfl_up(inclE, d); if ((int)lane >= d) inclE = tE > inclE ? tE : inclE; }
         u32 prevEnd = __shfl_up(inclE, 1); if (lane == 0) prevEnd = 0;
         if (lane == 63) D.waveTot[2][wave] = inclE;
-        __syncthreads();
+        lds_barrier();
         ZMI_DSTAMP(13);
         u32 baseE = cursor, totE = cursor;
 #pragma unroll
@@ -395,17 +403,13 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
         if (mine) {
             if (tid > 0) covLo |= D.covHi[tid - 1];                            // what the lane before this one did beyond its region
             if (cursor > rs) covLo |= cursor - rs >= 64 ? ~0ull : ((1ull << (cursor - rs)) - 1);     // a match from before the pass
-#ifdef ZMI_DBG_NOLINK
-            if (false) {
-#else
             if ((selLo | selHi) && tid > 0 && firstStart == D.lastEnd[tid - 1] && firstOff == (u32)D.lastOff[tid - 1]) {
-#endif
                 absorbed = firstLen;
                 if (selLo) selLo &= selLo - 1; else selHi &= selHi - 1;
             }
             D.cont[tid] = (u16)absorbed; D.more[tid] = (selLo | selHi) ? (u8)1 : (u8)0;
         }
-        __syncthreads();
+        lds_barrier();
         // ---- what every lane contributes: sequences; what every region holds: literals ----
         u32 ext = 0;
         if (mine && (selLo | selHi)) {
@@ -416,7 +420,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
         const u32 nMatch = popc64(selLo) + popc64(selHi), nKeep = popc64(keep);
         const u32 inclM = wave_scan_incl(nMatch), inclK = wave_scan_incl(nKeep);
         if (lane == 63) { D.waveTot[0][wave] = inclM; D.waveTot[1][wave] = inclK; }
-        __syncthreads();
+        lds_barrier();
         u32 baseM = 0, baseK = 0, totM = 0, totK = 0;
 #pragma unroll
         for (u32 k2 = 0; k2 < 16; ++k2) {
@@ -426,9 +430,6 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
         }
         ZMI_DSTAMP(14);
         if (mine) { D.keep[tid] = keep; D.keepExcl[tid] = baseK + inclK - nKeep; }
-#ifdef ZMI_DBG_KEEP
-        if (mine) { u64* dbg = reinterpret_cast<u64*>(candG + lo); dbg[tid * 4] = keep; dbg[tid * 4 + 1] = selLo; dbg[tid * 4 + 2] = selHi; dbg[tid * 4 + 3] = ((u64)eSpec << 32) | lastEnd; }
-#endif
         // ---- sequences: every lane emits its own, in order ----
         if (mine && nMatch) {
             u32 r = nbSeq + baseM + inclM - nMatch;
@@ -448,7 +449,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                 }
             }
         }
-        __syncthreads();
+        lds_barrier();
         // ---- literals: compacted in LDS first (the candidates' place: they are spent), then written out in whole 16-byte pieces:
         // on dense data the runs between matches are three or four bytes long, and a byte store to global memory each is what
         // this step would otherwise consist of.  32 positions per thread, two threads per region ----
@@ -476,7 +477,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                     }
                 }
             }
-            __syncthreads();
+            lds_barrier();
             u8* const dst = litOut + litBase;
             // (litBase is whatever earlier tiles left: the head brings the destination to 16-byte alignment)
             u32 head = (u32)((16 - ((uintptr_t)dst & 15)) & 15); if (head > totK) head = totK;
@@ -490,10 +491,13 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
             const u32 done = head + (body << 4);
             if (tid < totK - done) dst[done + tid] = S[done + tid];
         }
-        __syncthreads();
+        lds_barrier();
         ZMI_DSTAMP(15);
         cursor = totE; nbSeq += totM; litBase += totK;
     }
+#ifdef ZMI_LZ_STAMPS
+    if ((tid & 63u) == 0) for (int i = 0; i < 6; i++) atomicAdd(&g_lzStamps[10 + i], dAcc[i]);
+#endif
 }
 
 // MODE 0 = fast strategy (one 6-byte hash; levels 1-2 and the negative levels); 1 = doubleFast strategy (8-byte + SHORT-byte

@@ -1002,13 +1002,6 @@ int ZSTDMI_DCtx_getStageTimes(const ZSTD_DCtx* d, float* ms, const char** names,
     return n;
 }
 
-#ifdef ZMI_DBG_KEEP
-extern "C" size_t ZSTDMI_debugReadCand(ZSTD_CCtx* c, void* dst, size_t off, size_t n)
-{
-    (void)hipStreamSynchronize(c->stream);
-    return hipMemcpy(dst, (const u8*)c->cand.p + off, n, hipMemcpyDeviceToHost) == hipSuccess ? 0 : 1;
-}
-#endif
 size_t ZSTDMI_debugGetChunk(ZSTD_CCtx* c, size_t chunkIdx, ZSTDMI_Seq* seqs, size_t seqCap, size_t* nbSeq, void* lits, size_t litCap, size_t* litSize)
 {
     size_t e = cctx_bind(c); if (isErr(e)) return e;
