@@ -664,7 +664,6 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // Where the previous tile found next to nothing, this tile probes every 2nd or 4th position only — the reference's own
     // acceleration (ZSTD_fast's step = 1 + ((ip - anchor) >> kSearchStrength), U/ZstdFast.cs:130-136).  A match that starts
     // between probed positions is still picked up one or two bytes later and grown backward at emission.
-    u32 denseFrom = 0;                   // first tile of the part of the chunk that the region parse takes (0 = none)
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     u32 prevStride = 0;                  // the previous iteration's stride
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
@@ -1140,10 +1139,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         ZMI_STAMP(7);
         // a chunk whose first tile is dense in matches (text, source code, structured data) hands the rest of itself to the
         // region parse below: the tile loop verifies every position to keep one in eight
-        if (MODE == 0 && !DICT && !FAR && candAll && it == 0 && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > 2) { denseFrom = t; break; }
-    }
-    if (MODE == 0 && !DICT && !FAR && denseFrom) {
-        dense_rest(L, n, denseFrom, nTiles, candAll + (u64)c * kChunkSize, table, first, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+        if (MODE == 0 && !DICT && !FAR && it == 0) {
+            if (candAll && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > 2) {
+                dense_rest(L, n, t, nTiles, candAll + (u64)c * kChunkSize, table, first, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+                break;
+            }
+        }
     }
 #ifdef ZMI_LZ_STAMPS
     if ((tid & 63u) == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
