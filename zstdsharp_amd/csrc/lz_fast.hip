@@ -220,25 +220,31 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
     unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     // ---------------- I: candidates of every position, tile by tile ----------------
+    // A thread takes FOUR CONSECUTIVE positions: their 8-byte windows (and the 4 bytes in front, for the period test) come out of
+    // four aligned dwords with v_alignbyte, and their four candidates leave as one 8-byte store.
     for (u32 t = fromTile; t < nTiles; ++t) {
         const u32 tileStart = t * kTilePos;
         const u32 stamp = ((kChunkSize / kTilePos) - t - 1) << kTileLog;
+        const u32 q0 = 4 * tid, p0 = tileStart + q0;
+        const u32* const d32 = reinterpret_cast<const u32*>(L.in) + (p0 >> 2);
+        const u32 dm1 = d32[-1], d0 = d32[0], d1 = d32[1], d2 = d32[2];         // (p0 >= 4096: the dword in front exists)
         u64 w[kPPT]; u32 h[kPPT], cnd[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = tileStart + q;
-            valid[j] = p + 8 <= n; w[j] = 0; h[j] = 0; cnd[j] = 0;
+            const u32 p = p0 + j;
+            valid[j] = p + 8 <= n; h[j] = 0; cnd[j] = 0;
+            w[j] = (u64)__builtin_amdgcn_alignbyte(d1, d0, j) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, j) << 32);
             if (valid[j]) {
-                w[j] = lds_load8(L.in, p);
                 h[j] = hash6p(w[j]);
                 cnd[j] = table[hidx(h[j])];
-                atomicMin(&first[hidx(h[j])], ((stamp + q) << 16) | htag(h[j]));
+                atomicMin(&first[hidx(h[j])], ((stamp + q0 + j) << 16) | htag(h[j]));
             }
         }
         lds_barrier();
+        u64 out4 = 0;
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
-            const u32 q = j * kTile + tid, p = tileStart + q;
+            const u32 q = q0 + j, p = p0 + j;
             u32 cp = 0;                                   // candidate position + 1
             if (valid[j]) {
                 const u32 tag = htag(h[j]);
@@ -248,7 +254,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                 const bool i3 = __builtin_amdgcn_alignbyte(hi, lo, 3) == lo && ((hi ^ (hi >> 24)) & 0xFFu) == 0;
                 u32 per = 0;
                 if (i4 | i3) {                            // periods 1..4, as in the tile loop
-                    const u32 prev4 = lds_load4(L.in, p - 4);
+                    const u32 prev4 = __builtin_amdgcn_alignbyte(d0, dm1, j);
                     const bool i2 = i4 && ((lo ^ (lo >> 16)) & 0xFFFFu) == 0, i1 = i2 && ((lo ^ (lo >> 8)) & 0xFFu) == 0;
                     if (i4 && prev4 == lo) per = 4;
                     if (i3 && (prev4 >> 8) == (lo & 0xFFFFFFu)) per = 3;
@@ -263,8 +269,9 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                     else if (cnd[j] && (cnd[j] & 0xFFFFu) == tag) cp = cnd[j] >> 16;
                 }
             }
-            if (p < n) candG[p] = (u16)cp;
+            out4 |= (u64)(cp & 0xFFFFu) << (16 * j);
         }
+        if (p0 < n) *reinterpret_cast<u64*>(candG + p0) = out4;      // (entries behind the data's end are zero: no candidate)
         lds_barrier();                                    // (the tables; the candidates only have to have arrived before step II reads them)
     }
     __syncthreads();
