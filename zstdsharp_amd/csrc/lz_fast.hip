@@ -517,7 +517,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u16* __restrict__ candAll)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u32* __restrict__ regionList)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -671,6 +671,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // Where the previous tile found next to nothing, this tile probes every 2nd or 4th position only — the reference's own
     // acceleration (ZSTD_fast's step = 1 + ((ip - anchor) >> kSearchStrength), U/ZstdFast.cs:130-136).  A match that starts
     // between probed positions is still picked up one or two bytes later and grown backward at emission.
+    u32 regionCursor = 0;                // != 0: the chunk goes on in lz_region_kernel (parse cursor + 1)
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     u32 prevStride = 0;                  // the previous iteration's stride
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
@@ -1144,14 +1145,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         }
         t += nSub;
         ZMI_STAMP(7);
-        // a chunk whose first tile is dense in matches (text, source code, structured data) hands the rest of itself to the
-        // region parse below: the tile loop verifies every position to keep one in eight
-        if (MODE == 0 && !DICT && !FAR && it == 0) {
-            if (candAll && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > 2) {
-                dense_rest(L, n, t, nTiles, candAll + (u64)c * kChunkSize, table, first, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
-                break;
-            }
-        }
+        // a chunk whose first tile is dense in matches (text, source code, structured data) is finished by lz_region_kernel: this
+        // loop verifies every position to keep one in eight.  (A kernel of its own: with the region parse inlined here the tile
+        // loop itself ran 8 % slower on sparse data — code size.)
+        if (MODE == 0 && !DICT && !FAR && it == 0 && regionList && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > 2) { regionCursor = cursor + 1; break; }
     }
 #ifdef ZMI_LZ_STAMPS
     if ((tid & 63u) == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
@@ -1165,7 +1162,66 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             m.fhSize = bf == 0 ? frame_header_size64(fLen) + fhExtra : 0u;
         } else m.fhSize = frame_header_size(nData) + fhExtra;      // fhExtra: bytes of the dictID field (formatted dictionary), else 0
         m.litFromSrc = deferred ? 1u : 0u;       // (then nbSeq = 0 and litBase = nData: the literals are the chunk itself)
+        m.regionCursor = regionCursor;
         meta[c] = m;
+        if (regionCursor) regionList[1 + atomicAdd(&regionList[0], 1u)] = c;       // work list of lz_region_kernel: [count, chunks...]
+    }
+}
+
+// The rest of a dense chunk (see dense_rest): the chunk is staged again, the table gets the first tile's positions (the latest
+// occurrence per bucket, as the tile loop left it; the first-occurrence table starts empty: it only ever serves the tile that
+// filled it), and the region parse takes tiles 1 .. from the state lz_kernel recorded.
+__global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ src, u64 srcSize, Seq* __restrict__ seqs, u8* __restrict__ lits,
+                                                         ChunkMeta* __restrict__ meta, u16* __restrict__ candAll, const u32* __restrict__ regionList)
+{
+    extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
+    LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
+    const u32 tid = threadIdx.x, lane = lane_id(), wave = uniform(wave_id());
+    // one workgroup per CU walks the work list lz_kernel filled (its order is whatever the atomics made it; chunks are independent)
+    const u32 count = regionList[0];
+    for (u32 li = blockIdx.x; li < count; li += gridDim.x) {
+    const u32 c = regionList[1 + li];
+    const u32 rc = meta[c].regionCursor;
+    const u64 base = (u64)c * kChunkSize;
+    const u8* __restrict__ in = src + base;
+    const u32 n = (u32)((srcSize - base) < kChunkSize ? (srcSize - base) : kChunkSize);
+    if ((((uintptr_t)in) & 15) == 0) {
+        const uint4* in4 = reinterpret_cast<const uint4*>(in);
+        uint4* l4 = reinterpret_cast<uint4*>(L.in);
+        const u32 full = n >> 4;
+        uint4 v0, v1, v2, v3;
+        const u32 i0 = tid, i1 = tid + kTile, i2 = tid + 2 * kTile, i3 = tid + 3 * kTile;
+        v0 = in4[i0 < full ? i0 : 0]; v1 = in4[i1 < full ? i1 : 0]; v2 = in4[i2 < full ? i2 : 0]; v3 = in4[i3 < full ? i3 : 0];
+        if (i0 < full) l4[i0] = v0;
+        if (i1 < full) l4[i1] = v1;
+        if (i2 < full) l4[i2] = v2;
+        if (i3 < full) l4[i3] = v3;
+        for (u32 i = (full << 4) + tid; i < n; i += kTile) L.in[i] = in[i];
+    } else {
+        for (u32 i = tid; i < n; i += kTile) L.in[i] = in[i];
+    }
+    for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
+    u32* const table = L.tabMem;
+    u32* const first = L.tabMem + (1u << kHashLog);
+    {
+        uint4* const t4 = reinterpret_cast<uint4*>(L.tabMem);
+        const uint4 z = {0u, 0u, 0u, 0u}, f = {~0u, ~0u, ~0u, ~0u};
+#pragma unroll
+        for (u32 k = 0; k < 2; ++k) { t4[tid + k * kTile] = z; t4[2 * kTile + tid + k * kTile] = f; }
+    }
+    __syncthreads();
+#pragma unroll
+    for (u32 j = 0; j < kPPT; ++j) {                       // the first tile's positions into the table
+        const u32 p = j * kTile + tid;
+        if (p + 8 <= n) { const u32 hp = hash6p(lds_load8(L.in, p)); atomicMax(&table[hidx(hp)], ((p + 1) << 16) | htag(hp)); }
+    }
+    __syncthreads();
+    const ChunkMeta m0 = meta[c];
+    u32 cursor = rc - 1, nbSeq = m0.nbSeq, litBase = m0.litSize; bool deferred = m0.litFromSrc != 0;
+    const u32 nTiles = (n + kTilePos - 1) / kTilePos;
+    dense_rest(L, n, 1, nTiles, candAll + (u64)c * kChunkSize, table, first, seqs + (u64)c * kMaxSeq, lits + (u64)c * kLitStride, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+    if (tid == 0) { meta[c].nbSeq = nbSeq; meta[c].litSize = litBase; meta[c].litFromSrc = deferred ? 1u : 0u; }
+    __syncthreads();                                       // the next chunk takes over LDS
     }
 }
 
@@ -1181,7 +1237,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u32* regionList, hipStream_t stream)
 {
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
@@ -1190,7 +1246,7 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, regionList);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -1199,7 +1255,7 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // rounded up to whole 4 KiB tiles.  frameBlocks > 0: cross-chunk history instead (no dictionary): `frameBlocks` chunks of chunkBytes
 // form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream)
 {
     if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
         launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, stream);
@@ -1207,7 +1263,19 @@ void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u
     }
     if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, stream); break;
+        case 0:
+            if (cand) (void)hipMemsetAsync(regionList, 0, sizeof(u32), stream);
+            launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand ? regionList : nullptr, stream);
+            if (cand) {                                    // the dense chunks' rest: 256 workgroups (one per CU) walk the list
+                static bool attrSetR[64] = {};
+                int dev = 0; (void)hipGetDevice(&dev);
+                if (!attrSetR[dev & 63]) {
+                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_region_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+                    attrSetR[dev & 63] = true;
+                }
+                hipLaunchKernelGGL(lz_region_kernel, dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, regionList);
+            }
+            break;
         case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, nullptr, stream); break;
         default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, nullptr, stream); break;
         }

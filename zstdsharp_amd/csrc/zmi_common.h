@@ -50,6 +50,8 @@ struct ChunkMeta {
     u32 checksum;       // low 32 bits of XXH64 of the chunk when the checksum flag is set
     u32 rleByte;        // the byte of an RLE literals section
     u32 litFromSrc;     // 1 = the chunk has no sequences and its literals were never copied: they ARE the chunk's source bytes
+    u32 regionCursor;   // != 0: lz_kernel stopped behind the chunk's first tile (dense data); lz_region_kernel does the rest from
+                        // parse cursor regionCursor - 1 (nbSeq / litSize / litFromSrc hold the state after that tile)
 };
 
 // Huffman code table for one chunk (HBM): canonical codes as the reference assigns them (U/HufCompress.cs:750-788)

@@ -18,7 +18,7 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
@@ -242,7 +242,7 @@ static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
            c->total.ensure(64);
 }
 // the region parse of the fast strategy keeps one candidate position (u16) per input byte between its two steps (lz_fast.hip)
-static bool cctx_cand_workspace(ZSTD_CCtx* c, u32 nChunks) { return c->cand.ensure((size_t)nChunks * kChunkSize * sizeof(u16) + 256); }
+static bool cctx_cand_workspace(ZSTD_CCtx* c, u32 nChunks) { return c->cand.ensure((size_t)nChunks * kChunkSize * sizeof(u16) + 256 + ((size_t)nChunks + 1) * sizeof(u32)); }
 
 // upload a newly loaded dictionary; a formatted one is first validated on the device (ZSTD_loadCEntropy's checks are those of
 // ZSTD_loadDEntropy plus the symbol-coverage rules that only matter to an encoder reusing the tables) -> dictionary_corrupted
@@ -334,7 +334,7 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, s);      c->timer.mark("lz_fast", s);
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, regionParse ? (u32*)((u8*)c->cand.p + (size_t)passChunks * kChunkSize * sizeof(u16) + 256) : nullptr, s);      c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s);        c->timer.mark("huf_build", s);
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
