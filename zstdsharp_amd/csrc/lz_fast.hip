@@ -517,11 +517,17 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u32* __restrict__ regionList)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u32* __restrict__ regionList, const u32 nChunks)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
-    const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = uniform(wave_id());
+    const u32 tid = threadIdx.x, lane = lane_id(), wave = uniform(wave_id());
+    // A workgroup takes chunks blockIdx.x, + gridDim.x, ...: with one workgroup per CU (LDS) nothing else hides the load latency at
+    // the start of a chunk, so the NEXT chunk's bytes are fetched into registers while this one is parsed (plain chunks only:
+    // a dictionary or history in front of the chunk keeps the direct path).
+    constexpr bool kPrefetch = MODE == 0 && !DICT && !FAR;      // (the dual-hash finders have no 16 registers to spare)
+    uint4 pf0 = {0, 0, 0, 0}, pf1 = pf0, pf2 = pf0, pf3 = pf0; bool pfValid = false;
+    for (u32 c = blockIdx.x; c < nChunks; c += gridDim.x) {
     // Raw-content dictionary (row f-4; ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5126-5237): its last `prefixLen` bytes
     // sit in front of the chunk in LDS, ending at a tile boundary (hist = whole tiles of history, positions below lowLimit
     // are padding and never referenced).  History tiles run the probe/insert half of the loop only; the parse starts
@@ -546,7 +552,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #endif
 
     // ---- stage the chunk: 16 B per lane when the source is 16-byte aligned ----
-    if ((((uintptr_t)in) & 15) == 0) {
+    if (kPrefetch && pfValid) {                            // (uniform) a full aligned chunk, already in registers
+        uint4* l4 = reinterpret_cast<uint4*>(L.in);
+        l4[tid] = pf0; l4[tid + kTile] = pf1; l4[tid + 2 * kTile] = pf2; l4[tid + 3 * kTile] = pf3;
+    } else if ((((uintptr_t)in) & 15) == 0) {
         const uint4* in4 = reinterpret_cast<const uint4*>(in);
         uint4* l4 = reinterpret_cast<uint4*>(L.in + hist);
         const u32 full = nData >> 4;
@@ -586,6 +595,16 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         for (u32 k = 0; k < 2; ++k) { t4[tid + k * kTile] = MODE == 0 ? z : f; t4[2 * kTile + tid + k * kTile] = MODE == 0 ? f : z; }
     }
     if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.nzWords[2] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; L.matchCount[2] = 0; }
+    pfValid = false;
+    if (kPrefetch) {
+        const u32 cN = c + gridDim.x;
+        const u8* __restrict__ inN = src + (u64)cN * kChunkSize;
+        if (cN < nChunks && srcSize - (u64)cN * kChunkSize >= kChunkSize && (((uintptr_t)inN) & 15) == 0) {      // uniform
+            const uint4* n4 = reinterpret_cast<const uint4*>(inN);
+            pf0 = n4[tid]; pf1 = n4[tid + kTile]; pf2 = n4[tid + 2 * kTile]; pf3 = n4[tid + 3 * kTile];
+            pfValid = true;
+        }
+    }
     __syncthreads();
     if (FAR && farAvail) {
         // the table starts out holding the input in front of the block (what the reference's table still holds from the blocks
@@ -1166,6 +1185,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         meta[c] = m;
         if (regionCursor) regionList[1 + atomicAdd(&regionList[0], 1u)] = c;       // work list of lz_region_kernel: [count, chunks...]
     }
+    __syncthreads();                                       // the next chunk takes over LDS
+    }
 }
 
 // The rest of a dense chunk (see dense_rest): the chunk is staged again, the table gets the first tile's positions (the latest
@@ -1246,7 +1267,10 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(nChunks), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, regionList);
+    // (the fast finder on plain chunks: 4096 workgroups — 1024 balanced mixed data visibly worse —, each takes every 4096th chunk with the next one's bytes in flight; the hardware
+    //  still hands workgroups to CUs as they free up, which is what balances chunks of unequal cost.  Everything else: a workgroup per chunk)
+    const u32 grid = (MODE == 0 && !DICT && !FAR && nChunks > 4096) ? 4096u : nChunks;
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, regionList, nChunks);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
