@@ -322,7 +322,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
         // ---- step 1, speculative: where does the parse LEAVE this region?  The lane starts kWarm positions in front of its region
         // (the first region of a pass at the cursor it was handed): a greedy parse forgets where it started within a few matches,
         // so it usually leaves the region exactly where the parse that comes through the regions before it will.  Nothing is written ----
-        constexpr u32 kWarm = 32;
+        constexpr u32 kWarm = 16;
         const bool lastReg = tid + 1 == nReg;
         u32 eSpec = 0;
         if (mine) {
