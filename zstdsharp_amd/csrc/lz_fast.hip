@@ -209,35 +209,48 @@ struct DenseLds {                        // laid over the tile arrays (tileLen .
     u32 waveTot[3][16];                  // cross-wave scan: matches, kept literals, last end
 };
 
-__device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 fromTile, const u32 nTiles,
-                                           u16* __restrict__ candG, u32* const table, u32* const first,
-                                           Seq* __restrict__ seqOut, u8* __restrict__ litOut,
-                                           u32& cursor, u32& nbSeq, u32& litBase, bool& deferred, const u32 tid, const u32 lane, const u32 wave)
+// Tiles [tFrom, tTo) go into the hash tables exactly as the tile loop of lz_kernel would put them there (every position; the
+// latest occurrence per bucket for later tiles, the first occurrence within the tile for the tile itself), without verifying or
+// selecting anything.  From tile candFrom on, the POSITION (+ 1; 0 = none) of every position's candidate is written to candG
+// (a period 1..4, else the table candidates as the finder ranks them; tags checked, bytes not — the dual finders, whose table
+// entries carry no tag, keep the one of their four whose first 8 bytes agree furthest).
+// A thread takes FOUR CONSECUTIVE positions: their 8-byte windows (and the 4 bytes in front, for the period test) come out of
+// four aligned dwords with v_alignbyte, and their four candidates leave as one 8-byte store.
+// Used for: the history / dictionary tiles in front of a block (no candidates), and step I of the region parse.
+template <int MODE>
+__device__ __forceinline__ void insert_tiles(LzLds& L, const u32 n, const u32 tFrom, const u32 tTo, const u32 candFrom, const u32 lowLimit,
+                                             u16* __restrict__ candG, const u32 tid)
 {
-    static_assert(sizeof(DenseLds) <= sizeof(L.tileLen) + sizeof(L.tileOff) + sizeof(L.jump), "DenseLds must fit over tileLen .. jump");
-    DenseLds& D = *reinterpret_cast<DenseLds*>(&L.tileLen[0]);
-#ifdef ZMI_LZ_STAMPS
-    unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[6] = {0, 0, 0, 0, 0, 0};
-#endif
-    // ---------------- I: candidates of every position, tile by tile ----------------
-    // A thread takes FOUR CONSECUTIVE positions: their 8-byte windows (and the 4 bytes in front, for the period test) come out of
-    // four aligned dwords with v_alignbyte, and their four candidates leave as one 8-byte store.
-    for (u32 t = fromTile; t < nTiles; ++t) {
+    u32* const table = L.tabMem;                           // fast (see lz_kernel for the layouts)
+    u32* const first = L.tabMem + (1u << kHashLog);
+    u32* const firstL = L.tabMem;                          // dual
+    u32* const firstS = L.tabMem + (1u << (kHashLog - 1));
+    u16* const tableL = reinterpret_cast<u16*>(L.tabMem + (1u << kHashLog));
+    u16* const tableS = tableL + (1u << kHashLog);
+    for (u32 t = tFrom; t < tTo; ++t) {
         const u32 tileStart = t * kTilePos;
+        const bool wantCand = t >= candFrom;              // (uniform) earlier tiles only fill the tables
         const u32 stamp = ((kChunkSize / kTilePos) - t - 1) << kTileLog;
         const u32 q0 = 4 * tid, p0 = tileStart + q0;
         const u32* const d32 = reinterpret_cast<const u32*>(L.in) + (p0 >> 2);
-        const u32 dm1 = d32[-1], d0 = d32[0], d1 = d32[1], d2 = d32[2];         // (p0 >= 4096: the dword in front exists)
-        u64 w[kPPT]; u32 h[kPPT], cnd[kPPT]; bool valid[kPPT];
+        const u32 dm1 = p0 ? d32[-1] : 0u, d0 = d32[0], d1 = d32[1], d2 = d32[2];
+        u64 w[kPPT]; u32 h[kPPT], h2[kPPT], cnd[kPPT]; bool valid[kPPT];
 #pragma unroll
         for (u32 j = 0; j < kPPT; ++j) {
             const u32 p = p0 + j;
-            valid[j] = p + 8 <= n; h[j] = 0; cnd[j] = 0;
+            valid[j] = p + 8 <= n && p >= lowLimit; h[j] = 0; h2[j] = 0; cnd[j] = 0;
             w[j] = (u64)__builtin_amdgcn_alignbyte(d1, d0, j) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, j) << 32);
             if (valid[j]) {
-                h[j] = hash6p(w[j]);
-                cnd[j] = table[hidx(h[j])];
-                atomicMin(&first[hidx(h[j])], ((stamp + q0 + j) << 16) | htag(h[j]));
+                if (MODE == 0) {
+                    h[j] = hash6p(w[j]);
+                    cnd[j] = table[hidx(h[j])];
+                    atomicMin(&first[hidx(h[j])], ((stamp + q0 + j) << 16) | htag(h[j]));
+                } else {
+                    h[j] = hash8p(w[j]); h2[j] = hash_shortp<5>(w[j]);
+                    const u32 hL = hidx(h[j]), hS = hidx(h2[j]);
+                    cnd[j] = (u32)tableL[hL] | ((u32)tableS[hS] << 16);
+                    atomicMin(&firstL[hL >> 1], ((stamp + q0 + j) << 16) | htag(h[j])); atomicMin(&firstS[hS >> 1], ((stamp + q0 + j) << 16) | htag(h2[j]));
+                }
             }
         }
         lds_barrier();
@@ -247,13 +260,11 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
             const u32 q = q0 + j, p = p0 + j;
             u32 cp = 0;                                   // candidate position + 1
             if (valid[j]) {
-                const u32 tag = htag(h[j]);
-                atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | tag);
                 const u32 lo = (u32)w[j], hi = (u32)(w[j] >> 32);
                 const bool i4 = lo == hi;
                 const bool i3 = __builtin_amdgcn_alignbyte(hi, lo, 3) == lo && ((hi ^ (hi >> 24)) & 0xFFu) == 0;
                 u32 per = 0;
-                if (i4 | i3) {                            // periods 1..4, as in the tile loop
+                if ((i4 | i3) && wantCand && p >= lowLimit + 4) {     // periods 1..4, as in the tile loop
                     const u32 prev4 = __builtin_amdgcn_alignbyte(d0, dm1, j);
                     const bool i2 = i4 && ((lo ^ (lo >> 16)) & 0xFFFFu) == 0, i1 = i2 && ((lo ^ (lo >> 8)) & 0xFFu) == 0;
                     if (i4 && prev4 == lo) per = 4;
@@ -261,24 +272,70 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                     if (i2 && (prev4 >> 16) == (lo & 0xFFFFu)) per = 2;
                     if (i1 && (prev4 >> 24) == (lo & 0xFFu)) per = 1;
                 }
-                if (per) cp = p - per + 1;
-                else {
-                    const u32 f = first[hidx(h[j])];
-                    const u32 fq = (f >> 16) - stamp;
-                    if (fq < q && (f & 0xFFFFu) == tag) cp = tileStart + fq + 1;
-                    else if (cnd[j] && (cnd[j] & 0xFFFFu) == tag) cp = cnd[j] >> 16;
+                if (MODE == 0) {
+                    const u32 tag = htag(h[j]);
+                    atomicMax(&table[hidx(h[j])], ((p + 1) << 16) | tag);
+                    if (per) cp = p - per + 1;
+                    else if (wantCand) {
+                        const u32 f = first[hidx(h[j])];
+                        const u32 fq = (f >> 16) - stamp;
+                        if (fq < q && (f & 0xFFFFu) == tag) cp = tileStart + fq + 1;
+                        else if (cnd[j] && (cnd[j] & 0xFFFFu) == tag) cp = cnd[j] >> 16;
+                    }
+                } else {
+                    const u32 hL = hidx(h[j]), hS = hidx(h2[j]);
+                    const u32 eL = firstL[hL >> 1], eS = firstS[hS >> 1];
+                    const u32 fL = eL >> 16, fS = eS >> 16;
+                    if (fL == stamp + q) tableL[hL] = (u16)(p + 1);          // one writer per entry, as in the tile loop
+                    if (fS == stamp + q) tableS[hS] = (u16)(p + 1);
+                    if (per) cp = p - per + 1;
+                    else if (wantCand) {
+                        // the four candidates of the dual finder (same-tile / earlier, 8-byte / 5-byte hash); the table entries
+                        // carry no tag, so the one whose first 8 bytes agree furthest is kept (in this order on ties), from 4 up
+                        u32 best = 0, bestLen = 3;
+                        const u32 c0 = (fL - stamp < q && (eL & 0xFFFFu) == htag(h[j])) ? tileStart + (fL - stamp) + 1 : 0u;
+                        const u32 c1 = cnd[j] & 0xFFFFu;
+                        const u32 c2 = (fS - stamp < q && (eS & 0xFFFFu) == htag(h2[j])) ? tileStart + (fS - stamp) + 1 : 0u;
+                        const u32 c3 = cnd[j] >> 16;
+                        auto tryc = [&](u32 c) {
+                            if (!c || c == best) return;
+                            const u64 x = w[j] ^ lds_load8(L.in, c - 1);
+                            const u32 l8 = x ? (ctz64(x) >> 3) : 8u;
+                            if (l8 > bestLen) { bestLen = l8; best = c; }
+                        };
+                        tryc(c0); tryc(c1); tryc(c2); tryc(c3);
+                        cp = best;
+                    }
                 }
             }
             out4 |= (u64)(cp & 0xFFFFu) << (16 * j);
         }
-        if (p0 < n) *reinterpret_cast<u64*>(candG + p0) = out4;      // (entries behind the data's end are zero: no candidate)
+        if (wantCand && p0 < n) *reinterpret_cast<u64*>(candG + p0) = out4;      // (entries behind the data's end are zero: no candidate)
         lds_barrier();                                    // (the tables; the candidates only have to have arrived before step II reads them)
     }
+}
+
+// MODE as in lz_kernel (0 fast, 1 dual-hash, 2 dual-hash + lazy deferral).  hist / lowLimit: the history in front of the block in
+// LDS (positions below lowLimit are padding); insertFrom: first tile whose positions still have to go into the tables (lz_region_kernel
+// starts from empty tables: the history tiles and the block's first tile; inlined in lz_kernel: fromTile).
+template <int MODE>
+__device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 insertFrom, const u32 fromTile, const u32 nTiles, const u32 hist, const u32 lowLimit,
+                                           u16* __restrict__ candG,
+                                           Seq* __restrict__ seqOut, u8* __restrict__ litOut,
+                                           u32& cursor, u32& nbSeq, u32& litBase, bool& deferred, const u32 tid, const u32 lane, const u32 wave)
+{
+    static_assert(sizeof(DenseLds) <= sizeof(L.tileLen) + sizeof(L.tileOff) + sizeof(L.jump), "DenseLds must fit over tileLen .. jump");
+    DenseLds& D = *reinterpret_cast<DenseLds*>(&L.tileLen[0]);
+#ifdef ZMI_LZ_STAMPS
+    unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[6] = {0, 0, 0, 0, 0, 0};
+#endif
+    // ---------------- I: candidates of every position, tile by tile ----------------
+    insert_tiles<MODE>(L, n, insertFrom, nTiles, fromTile, lowLimit, candG, tid);
     __syncthreads();
     ZMI_DSTAMP(10);
     if (deferred) {                                       // (uniform) the bytes counted so far, out of LDS (see the tile loop)
         for (u32 q16 = tid * 16; q16 < litBase; q16 += kTile * 16) {
-            const uint4 v = *reinterpret_cast<const uint4*>(L.in + q16);
+            const uint4 v = *reinterpret_cast<const uint4*>(L.in + hist + q16);
             u32u* o = (u32u*)(litOut + q16);
             o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         }
@@ -319,6 +376,21 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
             if (l > n - p) l = n - p;
             return l >= 4 ? l : 0u;
         };
+        // lazy deferral (MODE 2; U/ZstdLazy.cs:1836-1870): the match at p yields to the one at p + 1 while that one gains more
+        // (4 bits per byte saved, minus log2 of the offset, plus 4 for the literal it costs)
+        auto lazy = [&](u32& p, u32& l, u32& cpos, const u32 bound) {
+            for (;;) {
+                if (p + 1 >= bound || p + 9 > n) break;
+                const u32 c2 = C[p + 1 - lo];
+                if (!c2) break;
+                const u32 l2 = verify(p + 1, c2 - 1);
+                if (!l2) break;
+                const int g1 = (int)(l * 4) - (int)highbit32(p - cpos + 1) + 4;
+                const int g2 = (int)(l2 * 4) - (int)highbit32(p + 1 - (c2 - 1) + 1);
+                if (g2 <= g1) break;
+                ++p; l = l2; cpos = c2 - 1;
+            }
+        };
         // ---- step 1, speculative: where does the parse LEAVE this region?  The lane starts kWarm positions in front of its region
         // (the first region of a pass at the cursor it was handed): a greedy parse forgets where it started within a few matches,
         // so it usually leaves the region exactly where the parse that comes through the regions before it will.  Nothing is written ----
@@ -336,7 +408,8 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                 p += skip;
                 if (p >= re) break;
                 const u32 cp = (u32)(c4 >> (16 * skip)) & 0xFFFFu;
-                const u32 l = (p + 8 <= n) ? verify(p, cp - 1) : 0u;
+                u32 l = (p + 8 <= n) ? verify(p, cp - 1) : 0u;
+                if (MODE == 2 && l) { u32 cq = cp - 1; lazy(p, l, cq, re); }
                 p += l ? l : 1u;
             }
             if (p < re) p = re;
@@ -368,10 +441,11 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 from
                 if (p + 8 > n) { ++p; continue; }
                 u32 cpos = cp - 1;
                 u32 l = verify(p, cpos);
+                if (MODE == 2 && l) lazy(p, l, cpos, bound);
                 if (!lastReg && p + l > eSpec) l = eSpec - p;
                 if (l < 4) { ++p; continue; }
                 const u32 off = p - cpos;
-                while (p > anchor && cpos > 0 && L.in[p - 1] == L.in[cpos - 1]) { --p; --cpos; ++l; }     // ZstdFast.cs:242-247
+                while (p > anchor && cpos > lowLimit && L.in[p - 1] == L.in[cpos - 1]) { --p; --cpos; ++l; }     // ZstdFast.cs:242-247
                 const u32 q = p - rs;                                    // 0 .. 126
                 {   // bytes [q, q + l) of the lane's stretch (a backward extension can make a match longer than the 64 verified bytes)
                     const u32 e = q + l;
@@ -517,7 +591,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u32* __restrict__ regionList, const u32 nChunks)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u16* __restrict__ candAll, u32* __restrict__ regionList, const u32 nChunks)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -530,7 +604,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     for (u32 c = blockIdx.x; c < nChunks; c += gridDim.x) {
     // Raw-content dictionary (row f-4; ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5126-5237): its last `prefixLen` bytes
     // sit in front of the chunk in LDS, ending at a tile boundary (hist = whole tiles of history, positions below lowLimit
-    // are padding and never referenced).  History tiles run the probe/insert half of the loop only; the parse starts
+    // are padding and never referenced).  History tiles only go into the tables (insert_tiles); the parse starts
     // with the cursor at `hist`, so everything after it is untouched: offsets simply reach back into the history.
     // chunkBytes = 64 KiB - hist (64 KiB without a dictionary).
     // Cross-chunk history (row f-1; the block loop's window, U/ZstdCompress.cs:4705-4807): frameBlocks > 0 makes every
@@ -694,16 +768,17 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     u32 prevStride = 0;                  // the previous iteration's stride
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
-    for (u32 t = lowLimit >> kTileLog, it = 0; t < nTiles; ++it) {      // (tiles wholly below lowLimit are padding)
+    // history / dictionary tiles (those wholly below lowLimit are padding) only fill the tables: searched, never parsed
+    if (DICT && lowLimit < hist) insert_tiles<MODE>(L, n, lowLimit >> kTileLog, hist >> kTileLog, 0xFFFFFFFFu, lowLimit, nullptr, tid);
+    for (u32 t = hist >> kTileLog, it = 0; t < nTiles; ++it) {
         const u32 tileStart = t * kTilePos;
-        const bool histTile = DICT && tileStart < hist;                                         // uniform: dictionary bytes, insert only
         // stride: every 2nd / 4th position after a sparse tile; where a strided iteration found next to nothing either, every
         // 8th, then every 16th (the reference's step keeps growing the same way while nothing matches, U/ZstdFast.cs:130-136)
         u32 strideSel = prevDensity < 8 ? 2u : (prevDensity < 32 ? 1u : 0u);            // uniform
         if (prevDensity < 4 && prevStride >= 2) strideSel = prevStride < 4 ? prevStride + 1 : 4u;
-        else if (prevDensity == 0 && !histTile && t != 0) strideSel = 3;                // nothing at all in the previous tile(s), whatever their stride
+        else if (prevDensity == 0 && t != 0) strideSel = 3;                // nothing at all in the previous tile(s), whatever their stride
         // negative levels (ZSTD_fast with a step, U/ZstdFast.cs:101-103): never denser than the step asks for; history is still inserted in full
-        if (strideSel < minStrideLog && !histTile) strideSel = minStrideLog;            // uniform
+        if (strideSel < minStrideLog) strideSel = minStrideLog;                          // uniform
         // Super-tile: where only every 2nd / 4th (8th, 16th) position is probed, TWO / FOUR tiles (as many as are left in
         // full) are taken in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies
         // overlap and the two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot
@@ -711,7 +786,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // whatever the number of matches (capped; what is left out stays literals).
         u32 nSubT = strideSel > 2 ? 4u : 1u << strideSel;          // at most 16 KiB per iteration: the stride adapts again after that
         { const u32 fullLeft = (n - tileStart) >> kTileLog; if (nSubT > fullLeft) nSubT = fullLeft; }
-        const bool super = nSubT >= 2 && !histTile;                                     // uniform
+        const bool super = nSubT >= 2;                                                  // uniform
         if (!super) { nSubT = 1; if (strideSel > 2) strideSel = 2; }                    // (a lone tile knows strides 1, 2, 4 only)
         const u32 strideLog = strideSel;
         span = nSubT << kTileLog;
@@ -854,7 +929,6 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     }
                 }
             }
-            if (histTile) len = 0;               // history is searched, never parsed
             if (MODE != 0 && SHORT == 4) {
                 // a 4-byte match far away costs more than its literals (offset bits + three codes against ~5 bits a byte)
                 if (len == 4 && off >= 256) len = 0;
@@ -904,8 +978,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             for (u32 j = 0; j < kPPT; ++j) if (valid[j]) atomicMax(&table[hidx(h[j])], ((tileStart + probed(j) + 1) << 16) | htag(h[j]));
         }
         // matches per 4096 positions had every position been probed
-        prevDensity = histTile ? 0xFFFFFFFFu : (matchCount << strideLog) / nSubT;     // history and the tile after it: every position
-        prevStride = histTile ? 0u : strideLog;
+        prevDensity = (matchCount << strideLog) / nSubT;
+        prevStride = strideLog;
         const bool any = matchCount != 0 && c0 < span;                   // uniform
         const bool dense = any && matchCount > 64 && !super;
         if (dense) {
@@ -1108,7 +1182,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
             litBase += bytes;
         } else {
-            if (deferred && !histTile) {         // (uniform) the first tile that is not all literals: the bytes counted so far, out of LDS
+            if (deferred) {         // (uniform) the first tile that is not all literals: the bytes counted so far, out of LDS
                 for (u32 q16 = tid * 16; q16 < litBase; q16 += kTile * 16) {
                     const uint4 v = *reinterpret_cast<const uint4*>(L.in + hist + q16);
                     u32u* o = (u32u*)(litOut + q16);             // (litBase is a multiple of 4096 here: whole tiles only)
@@ -1167,7 +1241,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // a chunk whose first tile is dense in matches (text, source code, structured data) is finished by lz_region_kernel: this
         // loop verifies every position to keep one in eight.  (A kernel of its own: with the region parse inlined here the tile
         // loop itself ran 8 % slower on sparse data — code size.)
-        if (MODE == 0 && !DICT && !FAR && it == 0 && regionList && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > 2) { regionCursor = cursor + 1; break; }
+        if (!FAR && regionList && tileStart == hist && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > (hist >> kTileLog) + 2) {      // uniform
+            if (MODE == 0 && !DICT) { regionCursor = cursor + 1; break; }
+            __syncthreads();
+            dense_rest<MODE>(L, n, t, t, nTiles, hist, lowLimit, candAll + (u64)c * kChunkSize, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+            break;
+        }
     }
 #ifdef ZMI_LZ_STAMPS
     if ((tid & 63u) == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_lzStamps[i], stampAcc[i]);
@@ -1189,9 +1268,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     }
 }
 
-// The rest of a dense chunk (see dense_rest): the chunk is staged again, the table gets the first tile's positions (the latest
-// occurrence per bucket, as the tile loop left it; the first-occurrence table starts empty: it only ever serves the tile that
-// filled it), and the region parse takes tiles 1 .. from the state lz_kernel recorded.
+// The rest of a dense chunk for the fast finder on plain chunks (see dense_rest): the chunk is staged again, the table gets the
+// first tile's positions (the latest occurrence per bucket, as the tile loop left it; the first-occurrence table starts empty: it
+// only ever serves the tile that filled it), and the region parse takes tiles 1 .. from the state lz_kernel recorded.
 __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ src, u64 srcSize, Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                          ChunkMeta* __restrict__ meta, u16* __restrict__ candAll, const u32* __restrict__ regionList)
 {
@@ -1223,7 +1302,6 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     u32* const table = L.tabMem;
-    u32* const first = L.tabMem + (1u << kHashLog);
     {
         uint4* const t4 = reinterpret_cast<uint4*>(L.tabMem);
         const uint4 z = {0u, 0u, 0u, 0u}, f = {~0u, ~0u, ~0u, ~0u};
@@ -1240,7 +1318,7 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
     const ChunkMeta m0 = meta[c];
     u32 cursor = rc - 1, nbSeq = m0.nbSeq, litBase = m0.litSize; bool deferred = m0.litFromSrc != 0;
     const u32 nTiles = (n + kTilePos - 1) / kTilePos;
-    dense_rest(L, n, 1, nTiles, candAll + (u64)c * kChunkSize, table, first, seqs + (u64)c * kMaxSeq, lits + (u64)c * kLitStride, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+    dense_rest<0>(L, n, 1, 1, nTiles, 0, 0, candAll + (u64)c * kChunkSize, seqs + (u64)c * kMaxSeq, lits + (u64)c * kLitStride, cursor, nbSeq, litBase, deferred, tid, lane, wave);
     if (tid == 0) { meta[c].nbSeq = nbSeq; meta[c].litSize = litBase; meta[c].litFromSrc = deferred ? 1u : 0u; }
     __syncthreads();                                       // the next chunk takes over LDS
     }
@@ -1258,19 +1336,27 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u32* regionList, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream)
 {
+    // the region parse of dense chunks: a second kernel behind a work list for the fast finder on plain chunks (with that code inlined
+    // its tile loop ran 8 % slower on sparse data — code size — and BASELINE's headline is sparse data at level 1), inlined otherwise
+    constexpr bool kSplit = MODE == 0 && !DICT && !FAR;
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (!attrSet[dev & 63]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+        if (kSplit) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_region_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
+    if (FAR) cand = nullptr;
+    if (cand && kSplit) (void)hipMemsetAsync(regionList, 0, sizeof(u32), stream);
     // (the fast finder on plain chunks: 4096 workgroups — 1024 balanced mixed data visibly worse —, each takes every 4096th chunk with the next one's bytes in flight; the hardware
     //  still hands workgroups to CUs as they free up, which is what balances chunks of unequal cost.  Everything else: a workgroup per chunk)
     const u32 grid = (MODE == 0 && !DICT && !FAR && nChunks > 4096) ? 4096u : nChunks;
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, regionList, nChunks);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, cand ? regionList : nullptr, nChunks);
+    if (kSplit && cand)                                    // the dense chunks' rest: 256 workgroups (one per CU) walk the list
+        hipLaunchKernelGGL(lz_region_kernel, dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, regionList);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -1278,37 +1364,26 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // prefix/prefixLen: the dictionary bytes every chunk sees as history (null/0 without one); chunkBytes = 64 KiB minus prefixLen
 // rounded up to whole 4 KiB tiles.  frameBlocks > 0: cross-chunk history instead (no dictionary): `frameBlocks` chunks of chunkBytes
 // form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.
+// cand / regionList (null: off): workspace of the region parse, 65536 u16 per chunk and 1 + nChunks u32.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream)
 {
     if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
-        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, stream);
+        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, stream);
         return;
     }
     if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
         switch (finder) {
-        case 0:
-            if (cand) (void)hipMemsetAsync(regionList, 0, sizeof(u32), stream);
-            launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand ? regionList : nullptr, stream);
-            if (cand) {                                    // the dense chunks' rest: 256 workgroups (one per CU) walk the list
-                static bool attrSetR[64] = {};
-                int dev = 0; (void)hipGetDevice(&dev);
-                if (!attrSetR[dev & 63]) {
-                    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_region_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
-                    attrSetR[dev & 63] = true;
-                }
-                hipLaunchKernelGGL(lz_region_kernel, dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, regionList);
-            }
-            break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, nullptr, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, nullptr, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, regionList, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, regionList, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, regionList, stream); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, nullptr, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, nullptr, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, nullptr, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, regionList, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, regionList, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, regionList, stream); break;
     }
 }
 

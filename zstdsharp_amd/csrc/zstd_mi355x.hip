@@ -322,7 +322,7 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
     u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
     if (frameBlocks && passChunks < totalChunks) { passChunks -= passChunks % frameBlocks; if (!passChunks) passChunks = frameBlocks; }     // frames never straddle passes
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
-    const bool regionParse = rs.finder == 0 && prefixLen == 0 && frameBlocks == 0 && rs.minStrideLog == 0;
+    const bool regionParse = rs.minStrideLog == 0 && !(rs.finder == 0 && frameBlocks && chunkBytes >= kChunkSize) && !getenv("ZSTDMI_NO_REGION");   // (not the far-candidate finder)
     if (regionParse && !cctx_cand_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy;      // ZSTD_selectEncodingType's < lazy heuristic is the one seq_encode holds (U/ZstdCompressSequences.cs:400-469): levels whose strategy is lazy or above get greedy's constants
     size_t produced = 0;
