@@ -236,6 +236,7 @@ def main():
     ap.add_argument("--gather-method", default="p2p", choices=["p2p", "padded"], help="N>1: exact-size grouped send/recv, or one padded all-gather + compaction")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parser", type=int, default=0, help="0 = region parse of dense chunks (default), 1 = tile loop only (ZSTDMI_CCtx_setParser)")
     ap.add_argument("--history", type=int, default=None, help="cross-chunk history in KiB per block (0 = independent 64 KiB frames; default: by level, "
                     "i.e. off at levels 1-2, 32 at levels >= 3)")
     args = ap.parse_args()
@@ -289,6 +290,8 @@ def main():
     lib.ZSTDMI_CCtx_setProfiling(c.cctx, 1); lib.ZSTDMI_DCtx_setProfiling(d.dctx, 1)
     if args.history is not None:
         assert lib.ZSTDMI_CCtx_setHistory(c.cctx, args.history << 10, 0) == 0
+    if args.parser:
+        assert lib.ZSTDMI_CCtx_setParser(c.cctx, args.parser) == 0
     comm = torch.cuda.Stream(device=dev) if world > 1 and not args.no_gather else None
     gathered = None
     # N > 1: the all-gather-v of step i runs on a side stream and overlaps the decompress of step i and the compress of step

@@ -131,6 +131,13 @@ size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* cctx, unsigned chunksPerPass);
  * off at levels 1-2 unless ZSTD_c_windowLog > 16 is set).  Ignored while a dictionary is loaded. */
 size_t ZSTDMI_CCtx_setHistory(ZSTD_CCtx* cctx, int historyBytes, unsigned frameBytes);
 
+/* parse of chunks that are dense in matches (text, source code, structured data): 0 = region parse (default: after a chunk's
+ * first 4 KiB tile found >= 384 matches, the candidates of every later position are looked up first and one lane per 64
+ * positions walks them the way ZSTD_compressBlock_fast walks a block, U/ZstdFast.cs:130-260), 1 = the tile loop for every chunk
+ * (each 4 KiB tile verified position by position and selected in parallel; slower on dense data, sizes within 0.5 %).
+ * Both produce valid, deterministic streams. */
+size_t ZSTDMI_CCtx_setParser(ZSTD_CCtx* cctx, unsigned mode);
+
 /* literal (Huffman) decoder: 0 = chosen by frame count (default), 1 = serial, 4 lanes per frame (highest throughput when
  * thousands of frames are in flight), 2 = self-synchronising, 256 lanes per frame (lowest latency per frame),
  * 3 = serial with compact tables (2 KiB + pair table per frame: twice the frames in flight) */

@@ -85,7 +85,7 @@ def test_parameters_without_a_device():
                                                  (102, (13, 0), (12, 17), (5, 31)),               # hashLog
                                                  (105, (6, 0), (5, 4), (2, 8)),                   # minMatch (fast strategy: 6)
                                                  (103, (12, 0), (13,), (5, 31)),                  # chainLog (level 1, <= 128 KiB: 12)
-                                                 (104, (1, 0), (2,), (31,))):                    # searchLog
+                                                 (104, (1, 2, 5, 30, 0), (), (31,))):              # searchLog (attempts of the level >= 5 search)
         for v in ok:
             c.SetParameter(param, v)
             assert c.GetParameter(param) == v

@@ -74,17 +74,19 @@ def test_negative_levels_store_raw_literals_and_round_trip(gpu_lib, oracle):
 
 def test_explicit_strategy_and_target_length_select_the_finder(gpu_lib, oracle):
     """ZSTD_c_strategy on top of a level (ZSTD_overrideCParams, U/ZstdCompress.cs:2096-2127): level 1 + doubleFast is level 3's
-    finder on a 64 KiB chunk, level 1 + greedy is level 5's; level 1 + targetLength behaves as the negative level of that step."""
+    finder on a 64 KiB chunk, level 1 + greedy is level 5's (given level 5's searchLog); level 1 + targetLength behaves as the negative level of that step."""
     data = datagen.gen("text", 200000, 5)
     def wrap(level, **params):
         with z.Compressor(level) as c:
             for k, v in params.items():
-                c.SetParameter({"strategy": ZSTD_c_strategy, "targetLength": ZSTD_c_targetLength}[k], v)
+                c.SetParameter({"strategy": ZSTD_c_strategy, "targetLength": ZSTD_c_targetLength, "searchLog": 104}[k], v)
             out = c.Wrap(data)
         assert oracle.decompress(out, len(data)) == data
         return out
     assert wrap(1, strategy=2) == wrap(3)
-    assert wrap(1, strategy=3) == wrap(5)
+    # (greedy on top of level 1 keeps level 1's searchLog: the level-5 finder with fewer attempts per position)
+    assert len(wrap(1, strategy=3)) < len(wrap(1, strategy=2)) and len(wrap(5)) <= len(wrap(1, strategy=3))
+    assert wrap(1, strategy=3, searchLog=5) == wrap(5, searchLog=5)
     assert wrap(3, strategy=1) == wrap(1)
     assert wrap(1, targetLength=5) == wrap(-5)
 

@@ -151,3 +151,32 @@ def test_history_frame_size_is_settable_and_frames_never_straddle_passes(gpu_lib
     with z.Compressor(1) as c:
         assert is_error(gpu_lib.ZSTDMI_CCtx_setHistory(c.cctx, 49 << 10, 0))
         assert is_error(gpu_lib.ZSTDMI_CCtx_setHistory(c.cctx, 0, 1000))
+
+
+@pytest.mark.parametrize("level,hist", [(1, 0), (3, -1), (5, -1), (3, 0), (5, 0), (5, 16 << 10)])
+@pytest.mark.parametrize("kind", ["text", "mixed", "pysrc"])
+def test_region_parse_and_tile_loop_both_restore_the_input_and_never_lose_more_than_one_percent(gpu_lib, oracle, level, hist, kind):
+    """ZSTDMI_CCtx_setParser: dense chunks are parsed region by region (one lane per 64 positions over precomputed candidates: the
+    walk of U/ZstdFast.cs:130-260, at level >= 5 with the lazy step of U/ZstdLazy.cs:1836-1870) or by the tile loop like every
+    other chunk.  Both are valid parses: the oracle's decoder restores the input from either, each is deterministic, and the
+    sizes differ by well under one percent where both see the same candidates (levels below 5)."""
+    n = (1 << 20) + 12345
+    if kind == "pysrc":
+        import inspect, collections, argparse, ast as _ast
+        data = ("".join(inspect.getsource(m) for m in (collections, argparse, _ast, inspect)).encode() * 4)[:n]
+        n = len(data)
+    else:
+        data = datagen.gen(kind, n, 33)
+    sizes = {}
+    with z.Compressor(level) as c, z.Decompressor() as d:
+        set_history(gpu_lib, c, hist)
+        for parser in (0, 1):
+            assert gpu_lib.ZSTDMI_CCtx_setParser(c.cctx, parser) == 0
+            comp = c.Wrap(data)
+            assert comp == c.Wrap(data), "deterministic"
+            assert oracle.decompress(comp, n) == data
+            assert d.Unwrap(comp) == data
+            sizes[parser] = len(comp)
+        assert gpu_lib.ZSTDMI_CCtx_setParser(c.cctx, 2) != 0
+    # (level >= 5: the region parse searches hash chains eight deep, the tile loop knows four candidates: it may only be smaller)
+    assert sizes[0] <= 1.01 * sizes[1] and (level >= 5 or sizes[1] <= 1.01 * sizes[0]), sizes

@@ -292,18 +292,20 @@ __device__ __forceinline__ void insert_tiles(LzLds& L, const u32 n, const u32 tF
                     else if (wantCand) {
                         // the four candidates of the dual finder (same-tile / earlier, 8-byte / 5-byte hash); the table entries
                         // carry no tag, so the one whose first 8 bytes agree furthest is kept (in this order on ties), from 4 up
+                        u32 cc[4];
+                        cc[0] = (fL - stamp < q && (eL & 0xFFFFu) == htag(h[j])) ? tileStart + (fL - stamp) + 1 : 0u;
+                        cc[1] = cnd[j] & 0xFFFFu;
+                        cc[2] = (fS - stamp < q && (eS & 0xFFFFu) == htag(h2[j])) ? tileStart + (fS - stamp) + 1 : 0u;
+                        cc[3] = cnd[j] >> 16;
+                        u64 x[4];                          // all four reads in flight together (no candidate: position 0, result dropped)
+#pragma unroll
+                        for (u32 k = 0; k < 4; ++k) x[k] = w[j] ^ lds_load8(L.in, cc[k] ? cc[k] - 1 : 0u);
                         u32 best = 0, bestLen = 3;
-                        const u32 c0 = (fL - stamp < q && (eL & 0xFFFFu) == htag(h[j])) ? tileStart + (fL - stamp) + 1 : 0u;
-                        const u32 c1 = cnd[j] & 0xFFFFu;
-                        const u32 c2 = (fS - stamp < q && (eS & 0xFFFFu) == htag(h2[j])) ? tileStart + (fS - stamp) + 1 : 0u;
-                        const u32 c3 = cnd[j] >> 16;
-                        auto tryc = [&](u32 c) {
-                            if (!c || c == best) return;
-                            const u64 x = w[j] ^ lds_load8(L.in, c - 1);
-                            const u32 l8 = x ? (ctz64(x) >> 3) : 8u;
-                            if (l8 > bestLen) { bestLen = l8; best = c; }
-                        };
-                        tryc(c0); tryc(c1); tryc(c2); tryc(c3);
+#pragma unroll
+                        for (u32 k = 0; k < 4; ++k) {
+                            const u32 l8 = x[k] ? (ctz64(x[k]) >> 3) : 8u;
+                            if (cc[k] && l8 > bestLen) { bestLen = l8; best = cc[k]; }
+                        }
                         cp = best;
                     }
                 }
@@ -315,22 +317,194 @@ __device__ __forceinline__ void insert_tiles(LzLds& L, const u32 n, const u32 tF
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Hash-chain search for level >= 5 (MODE 2), the place of ZSTD_HcFindBestMatch / ZSTD_RowFindBestMatch behind the greedy and
+// lazy parsers (U/ZstdLazy.cs:619-760, 1101-1309; searchLog 3 at this level and size, U/Clevels.cs): every position is linked to
+// an earlier position with the same 5-byte hash — the most recent one in front of its 64-position group — and a position's
+// candidate is the LONGEST match among the first `depth` (1 << searchLog, as the reference's nbAttempts) positions down its chain (the reference's chain table,
+// ZSTD_insertAndFindFirstIndex_internal, U/ZstdLazy.cs:572-617, walked as in :660-720).
+// The reference builds the chain by walking the input in order.  Here all threads hash a tile's 4096 positions, then ONE wave
+// takes the tile's 64 groups of 64 consecutive positions in order: read the table (latest occurrence so far) -> that is the
+// link; then ds_max the group's own positions into the table.  LDS operations of one wave execute in program order, so a group
+// sees every group before it and nothing of itself: deterministic, no sort, 64 x 4 LDS instructions per tile.  (Exact links —
+// a stable radix sort of the tile by hash, neighbours in sorted order — were built first and measured: 7.3 us per tile against
+// 1.5 for this, for 0.2 - 1.4 % of compressed size on the CPU model of this parse, tools/finder_lab.c.)
+// Links of the current tile and the three before it stay in LDS, all links go to global memory (2 bytes per position, L2), where
+// the walk follows them further back.
+// Measured with tools/finder_lab.c (same parse on the CPU): chains of depth 8 against one candidate per position: -7 % compressed
+// size on text, -11 % on Python sources.
+// ---------------------------------------------------------------------------------------------------------------------
+constexpr u32 kHcCont  = 12;             // a position whose left neighbour holds a match this long takes its continuation unsearched
+struct HcLds {                           // laid over the 64 KiB of the hash tables
+    u32 table[1u << kHashLog];           // position + 1 of the hash's latest occurrence so far (0 = none)
+    u16 hashes[kTilePos];                // the tile's hashes (0xFFFF: not a position to link)
+    u16 pred[kTilePos];                  // the tile's links (position + 1, 0 = none)
+    u16 spare[2 * kTilePos];
+};
+static_assert(sizeof(HcLds) == sizeof(u32) * (2u << kHashLog), "HcLds fills the tables' place");
+
+__device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom, const u32 tTo, const u32 candFrom, const u32 lowLimit, const u32 depth,
+                                         u16* __restrict__ candG, u16* __restrict__ chainG, const u32 tid, const u32 lane, const u32 wave
+#ifdef ZMI_LZ_STAMPS
+                                         , unsigned long long* dAcc, unsigned long long& dLast
+#endif
+                                         )
+{
+    HcLds& Hc = *reinterpret_cast<HcLds*>(L.tabMem);
+    // the links of the three tiles before the current one stay in LDS too (over the tile loop's arrays, idle here)
+    constexpr u32 kRing = 3;
+    u16* const ring = reinterpret_cast<u16*>(&L.tileLen[0]);
+    static_assert(offsetof(LzLds, tileLen) + kRing * kTilePos * sizeof(u16) <= sizeof(LzLds), "link ring must fit behind the tables");
+    u16* const tilePred = Hc.pred;
+    {   // no occurrences yet
+        uint4* const t4 = reinterpret_cast<uint4*>(Hc.table);
+        t4[tid] = uint4{0u, 0u, 0u, 0u}; t4[tid + kTile] = uint4{0u, 0u, 0u, 0u};
+    }
+    for (u32 t = tFrom; t < tTo; ++t) {
+        const u32 tileStart = t * kTilePos;
+        const u32 q0 = 4 * tid, p0 = tileStart + q0;
+        const u32* const d32 = reinterpret_cast<const u32*>(L.in) + (p0 >> 2);
+        const u32 dm1 = p0 ? d32[-1] : 0u, d0 = d32[0], d1 = d32[1], d2 = d32[2], d3 = d32[3], d4 = d32[4];
+        u64 a1[4], a2[4]; bool valid[4];
+        {   // ---- hashes: four consecutive positions per thread ----
+            u64 h4 = 0;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                const u32 p = p0 + j;
+                a1[j] = (u64)__builtin_amdgcn_alignbyte(d1, d0, j) | ((u64)__builtin_amdgcn_alignbyte(d2, d1, j) << 32);
+                a2[j] = (u64)__builtin_amdgcn_alignbyte(d3, d2, j) | ((u64)__builtin_amdgcn_alignbyte(d4, d3, j) << 32);
+                valid[j] = p + 8 <= n && p >= lowLimit;
+                h4 |= (u64)(valid[j] ? hidx(hash_shortp<5>(a1[j])) : 0xFFFFu) << (16 * j);
+            }
+            *reinterpret_cast<u64*>(&Hc.hashes[q0]) = h4;
+        }
+        ZMI_DSTAMP(10);
+        lds_barrier();
+        // ---- links: one wave, group after group (see above); four groups' reads and updates per step ----
+        if (wave == 0) {                                   // eight groups per step, the next step's hashes already on their way
+            u32 hn[8];
+#pragma unroll
+            for (u32 k = 0; k < 8; ++k) hn[k] = Hc.hashes[k * 64 + lane];
+#pragma unroll 1
+            for (u32 g = 0; g < 64; g += 8) {
+                u32 h[8], pv[8];
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) h[k] = hn[k];
+                if (g + 8 < 64) {
+#pragma unroll
+                    for (u32 k = 0; k < 8; ++k) hn[k] = Hc.hashes[(g + 8 + k) * 64 + lane];
+                }
+                u32 hx[8], val[8];                         // (branch-free: a position that is not linked adds 0 to bucket 0)
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) { const bool link = h[k] != 0xFFFFu; hx[k] = link ? h[k] : 0u; val[k] = link ? tileStart + (g + k) * 64 + lane + 1 : 0u; }
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) { pv[k] = Hc.table[hx[k]]; atomicMax(&Hc.table[hx[k]], val[k]); }
+#pragma unroll
+                for (u32 k = 0; k < 8; ++k) tilePred[(g + k) * 64 + lane] = (u16)(val[k] ? pv[k] : 0u);
+            }
+        }
+        lds_barrier();
+        ZMI_DSTAMP(11);
+        if (tid < 512) reinterpret_cast<uint4*>(chainG + tileStart)[tid] = reinterpret_cast<const uint4*>(tilePred)[tid];
+        // ---- search ----
+        if (t >= candFrom) {                               // uniform
+            u32 c[4], best[4], bestLen[4];
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                const u32 p = p0 + j;
+                best[j] = 0; bestLen[j] = 3; c[j] = valid[j] ? (u32)tilePred[q0 + j] : 0u;
+                const u32 lo = (u32)a1[j], hi = (u32)(a1[j] >> 32);
+                const bool i4 = lo == hi;
+                const bool i3 = __builtin_amdgcn_alignbyte(hi, lo, 3) == lo && ((hi ^ (hi >> 24)) & 0xFFu) == 0;
+                if ((i4 | i3) && valid[j] && p >= lowLimit + 4) {   // periods 1..4 (runs, tiny patterns): the candidate is the period itself
+                    const u32 prev4 = __builtin_amdgcn_alignbyte(d0, dm1, j);
+                    const bool i2 = i4 && ((lo ^ (lo >> 16)) & 0xFFFFu) == 0, i1 = i2 && ((lo ^ (lo >> 8)) & 0xFFu) == 0;
+                    u32 per = 0;
+                    if (i4 && prev4 == lo) per = 4;
+                    if (i3 && (prev4 >> 8) == (lo & 0xFFFFFFu)) per = 3;
+                    if (i2 && (prev4 >> 16) == (lo & 0xFFFFu)) per = 2;
+                    if (i1 && (prev4 >> 24) == (lo & 0xFFu)) per = 1;
+                    if (per) { best[j] = p - per + 1; bestLen[j] = 64; c[j] = 0; }
+                }
+            }
+            // A candidate can only beat the best so far if it agrees with the position on the four bytes that END one past the
+            // best length (the reference's own filter, U/ZstdLazy.cs:690-696): one unaligned dword per candidate instead of sixteen
+            // bytes; only those that pass are measured in full.  pw = those four bytes of the position.
+            // The four positions of a thread are searched one after the other: a position whose left neighbour found kHcCont
+            // bytes or more takes that match's continuation (same offset, one byte shorter) without a search of its own — the
+            // parse only ever looks at such a position for the lazy step, which a match that long does not lose
+            // (tools/finder_lab.c: 0.1 - 0.4 % of compressed size).  LDS gathers are what the search costs; this halves them.
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) {
+                const u32 p = p0 + j;
+                if (j > 0 && c[j] && best[j - 1] && bestLen[j - 1] >= kHcCont && bestLen[j - 1] < 64) {
+                    best[j] = best[j - 1] + 1; bestLen[j] = bestLen[j - 1] - 1; c[j] = 0;
+                }
+                u32 pw = (u32)a1[j];
+#pragma unroll 1
+                for (u32 d = 0; d < depth && c[j]; ++d) {
+                    const u32 cpos = c[j] - 1;
+                    const u32 chk = lds_load4(L.in, cpos + bestLen[j] - 3);
+                    const u32 nxt = cpos >= tileStart ? (u32)tilePred[cpos - tileStart]
+                                  : cpos + kRing * kTilePos >= tileStart ? (u32)ring[((cpos >> kTileLog) % kRing) * kTilePos + (cpos & (kTilePos - 1))]
+                                  : (u32)chainG[cpos];
+                    if (chk == pw) {
+                        u64 c1, c2;
+                        lds_load16(L.in, cpos, c1, c2);
+                        const u64 x1 = a1[j] ^ c1, x2 = a2[j] ^ c2;
+                        u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
+                        if (l == 16) {
+                            while (l < 64) {
+                                const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
+                                if (x) { l += ctz64(x) >> 3; break; }
+                                l += 8;
+                            }
+                            if (l > 64) l = 64;
+                        }
+                        if (l > n - p) l = n - p;
+                        if (l > bestLen[j]) { bestLen[j] = l; best[j] = c[j]; pw = lds_load4(L.in, p + l - 3); }
+                    }
+                    c[j] = bestLen[j] >= 64 ? 0u : nxt;
+                }
+            }
+            u64 out4 = 0;
+#pragma unroll
+            for (u32 j = 0; j < 4; ++j) out4 |= (u64)(best[j] & 0xFFFFu) << (16 * j);
+            if (p0 < n) *reinterpret_cast<u64*>(candG + p0) = out4;
+        }
+        lds_barrier();                                     // (the search is done with the ring slot this tile takes over)
+        if (tid < 512) reinterpret_cast<uint4*>(ring + (t % kRing) * kTilePos)[tid] = reinterpret_cast<const uint4*>(tilePred)[tid];
+        // the links in global memory are read by tiles at least kRing + 1 after this one: every kRing-th tile waits for the stores
+        if (t % kRing == kRing - 1) __syncthreads(); else lds_barrier();
+        ZMI_DSTAMP(13);
+    }
+}
+
 // MODE as in lz_kernel (0 fast, 1 dual-hash, 2 dual-hash + lazy deferral).  hist / lowLimit: the history in front of the block in
 // LDS (positions below lowLimit are padding); insertFrom: first tile whose positions still have to go into the tables (lz_region_kernel
 // starts from empty tables: the history tiles and the block's first tile; inlined in lz_kernel: fromTile).
 template <int MODE>
 __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 insertFrom, const u32 fromTile, const u32 nTiles, const u32 hist, const u32 lowLimit,
-                                           u16* __restrict__ candG,
+                                           u16* __restrict__ candG, u16* __restrict__ chainG, const u32 hcDepth,
                                            Seq* __restrict__ seqOut, u8* __restrict__ litOut,
                                            u32& cursor, u32& nbSeq, u32& litBase, bool& deferred, const u32 tid, const u32 lane, const u32 wave)
 {
     static_assert(sizeof(DenseLds) <= sizeof(L.tileLen) + sizeof(L.tileOff) + sizeof(L.jump), "DenseLds must fit over tileLen .. jump");
     DenseLds& D = *reinterpret_cast<DenseLds*>(&L.tileLen[0]);
+    // positions of a pass's matches by rank: behind DenseLds, over what is left of the tile loop's arrays (all idle by now)
+    constexpr u32 kMaxPassSeq = (kPassPos + 64) / 4 + 8;
+    static_assert(offsetof(LzLds, tileLen) + sizeof(DenseLds) + kMaxPassSeq * sizeof(u16) <= sizeof(LzLds), "rank list must fit behind DenseLds");
+    u16* const rankPos = reinterpret_cast<u16*>(reinterpret_cast<u8*>(&D) + sizeof(DenseLds));
 #ifdef ZMI_LZ_STAMPS
     unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[6] = {0, 0, 0, 0, 0, 0};
 #endif
     // ---------------- I: candidates of every position, tile by tile ----------------
-    insert_tiles<MODE>(L, n, insertFrom, nTiles, fromTile, lowLimit, candG, tid);
+    if constexpr (MODE == 2) hc_tiles(L, n, lowLimit >> kTileLog, nTiles, fromTile, lowLimit, hcDepth, candG, chainG, tid, lane, wave
+#ifdef ZMI_LZ_STAMPS
+                                      , dAcc, dLast
+#endif
+                                      );
+    else insert_tiles<MODE>(L, n, insertFrom, nTiles, fromTile, lowLimit, candG, tid);      // (MODE 2 always comes with its chain plane)
     __syncthreads();
     ZMI_DSTAMP(10);
     if (deferred) {                                       // (uniform) the bytes counted so far, out of LDS (see the tile loop)
@@ -466,18 +640,16 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
             D.lastEnd[tid] = lastEnd; D.lastOff[tid] = (u16)lastOff; D.covHi[tid] = covHi;
         }
         ZMI_DSTAMP(13);
-        // ---- ends of the matches so far, over the regions (prefix maximum): where the literals in front of a region's first match begin ----
-        u32 inclE = lastEnd;
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const u32 tE = __shfl_up(inclE, d); if ((int)lane >= d) inclE = tE > inclE ? tE : inclE; }
-        u32 prevEnd = __shfl_up(inclE, 1); if (lane == 0) prevEnd = 0;
-        if (lane == 63) D.waveTot[2][wave] = inclE;
+        // ---- where the pass's last match ends (the next pass's cursor) ----
+        {
+            const u32 wE = wave_max(lastEnd);
+            if (lane == 0) D.waveTot[2][wave] = wE;
+        }
         lds_barrier();
         ZMI_DSTAMP(13);
-        u32 baseE = cursor, totE = cursor;
+        u32 totE = cursor;
 #pragma unroll
-        for (u32 k2 = 0; k2 < 16; ++k2) { const u32 e = D.waveTot[2][k2]; if (k2 < wave) baseE = e > baseE ? e : baseE; totE = e > totE ? e : totE; }
-        prevEnd = prevEnd > baseE ? prevEnd : baseE;                          // end of the last match that starts before this lane's stretch
+        for (u32 k2 = 0; k2 < 16; ++k2) { const u32 e = D.waveTot[2][k2]; totE = e > totE ? e : totE; }
         // ---- links: a lane's first match that starts exactly where the match before it ends, with the same offset, is that
         // match going on (a long match or a run comes out of the lanes as a chain of pieces): the chain's head owns it ----
         u32 absorbed = 0;
@@ -511,24 +683,25 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
         }
         ZMI_DSTAMP(14);
         if (mine) { D.keep[tid] = keep; D.keepExcl[tid] = baseK + inclK - nKeep; }
-        // ---- sequences: every lane emits its own, in order ----
+        // ---- sequences.  A lane's matches have consecutive ranks, so lanes storing their own records hit 64 different cache lines
+        // per store instruction (measured: a tenth of the kernel on text).  Instead every lane files the POSITIONS of its matches
+        // by rank (and adds to its last match what the lanes after it continue), and after a barrier the whole workgroup builds
+        // the records rank by rank: consecutive lanes, consecutive records, whole lines.  The literals in front of a match run
+        // from the end of the match one rank below it (the first of the pass: from the cursor the pass was entered with) ----
         if (mine && nMatch) {
-            u32 r = nbSeq + baseM + inclM - nMatch;
-            u32 pe = prevEnd;
-            if (absorbed) pe = firstStart + firstLen;                             // (the absorbed piece is the head's; literals count from its end)
-#pragma unroll 1
-            for (u32 hw = 0; hw < 2; ++hw) {
-                u64 b = hw ? selHi : selLo;
-                while (b) {
-                    const u32 bit = ctz64(b); b &= b - 1;
-                    const u32 sPos = rs + 64 * hw + bit;
-                    const u32 off = C[sPos - lo]; u32 l = C[sPos - lo + 1];
-                    if (!b && (hw || !selHi)) l += ext;                           // the lane's last match: what the lanes after it add
-                    Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(sPos - pe); sq.mlBase = (u16)(l - 3);
-                    seqOut[r++] = sq;
-                    pe = sPos + l;
-                }
-            }
+            u32 r = baseM + inclM - nMatch, lastQ = 0;
+            u64 bLo = selLo, bHi = selHi;
+            while (bLo) { lastQ = ctz64(bLo); bLo &= bLo - 1; rankPos[r++] = (u16)(rs - lo + lastQ); }
+            while (bHi) { lastQ = 64u + ctz64(bHi); bHi &= bHi - 1; rankPos[r++] = (u16)(rs - lo + lastQ); }
+            if (ext) C[rs - lo + lastQ + 1] = (u16)(C[rs - lo + lastQ + 1] + ext);
+        }
+        lds_barrier();
+        for (u32 k = tid; k < totM; k += kTile) {
+            const u32 pos = rankPos[k], prev = k ? rankPos[k - 1] : 0u;
+            const u32 off = C[pos], len = C[pos + 1], plen = C[prev + 1];
+            const u32 pe = k ? lo + prev + plen : cursor;
+            Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(lo + pos - pe); sq.mlBase = (u16)(len - 3);
+            seqOut[nbSeq + k] = sq;
         }
         lds_barrier();
         // ---- literals: compacted in LDS first (the candidates' place: they are spent), then written out in whole 16-byte pieces:
@@ -546,14 +719,14 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
                     if (k32 == 0xFFFFFFFFu) {             // nothing matched here: 32 bytes straight through
                         const uint4 v0 = *reinterpret_cast<const uint4*>(L.in + pos0), v1 = *reinterpret_cast<const uint4*>(L.in + pos0 + 16);
                         u32u* o4 = (u32u*)o; o4[0] = v0.x; o4[1] = v0.y; o4[2] = v0.z; o4[3] = v0.w; o4[4] = v1.x; o4[5] = v1.y; o4[6] = v1.z; o4[7] = v1.w;
-                    } else {
-                        while (k32) {                     // run by run: a run of set bits is a run of literals
-                            const u32 b0 = (u32)__builtin_ctz(k32);
-                            const u32 inv = ~(k32 >> b0);
-                            const u32 len = inv ? (u32)__builtin_ctz(inv) : 32u - b0;
-                            for (u32 i = 0; i < len; ++i) o[i] = L.in[pos0 + b0 + i];
-                            o += len;
-                            k32 = (len + b0 >= 32) ? 0u : (k32 & (0xFFFFFFFFu << (b0 + len)));
+                    } else {                              // dword by dword out of registers: stores only, nothing waits on LDS
+                        const uint4 v0 = *reinterpret_cast<const uint4*>(L.in + pos0), v1 = *reinterpret_cast<const uint4*>(L.in + pos0 + 16);
+                        const u32 d[8] = { v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w };
+#pragma unroll
+                        for (u32 k = 0; k < 8; ++k) {
+                            const u32 keep = (k32 >> (4 * k)) & 0xFu, w4 = d[k];
+                            if (keep == 0xFu) { *(u32u*)o = w4; o += 4; }
+                            else { if (keep & 1) *o++ = (u8)w4; if (keep & 2) *o++ = (u8)(w4 >> 8); if (keep & 4) *o++ = (u8)(w4 >> 16); if (keep & 8) *o++ = (u8)(w4 >> 24); }
                         }
                     }
                 }
@@ -591,7 +764,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u16* __restrict__ candAll, u32* __restrict__ regionList, const u32 nChunks)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u16* __restrict__ candAll, u16* __restrict__ chainAll, u32* __restrict__ regionList, const u32 nChunks)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -626,6 +799,22 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #endif
 
     // ---- stage the chunk: 16 B per lane when the source is 16-byte aligned ----
+    if (DICT && frameBlocks && ((((uintptr_t)prefix) | lowLimit) & 15) == 0) {
+        // cross-chunk history: the history and the block are ONE contiguous piece of the input (at most 64 KiB): four 16-byte
+        // pieces per thread, all loads in flight before the first store (pieces past the end re-read piece 0 and are not stored)
+        const uint4* in4 = reinterpret_cast<const uint4*>(prefix);
+        uint4* l4 = reinterpret_cast<uint4*>(L.in + lowLimit);
+        const u32 bytes = prefixLen + nData, full = bytes >> 4;
+        uint4 v0, v1, v2, v3;
+        const u32 i0 = tid, i1 = tid + kTile, i2 = tid + 2 * kTile, i3 = tid + 3 * kTile;
+        v0 = in4[i0 < full ? i0 : 0]; v1 = in4[i1 < full ? i1 : 0]; v2 = in4[i2 < full ? i2 : 0]; v3 = in4[i3 < full ? i3 : 0];
+        if (i0 < full) l4[i0] = v0;
+        if (i1 < full) l4[i1] = v1;
+        if (i2 < full) l4[i2] = v2;
+        if (i3 < full) l4[i3] = v3;
+        for (u32 i = (full << 4) + tid; i < bytes; i += kTile) L.in[lowLimit + i] = prefix[i];
+        for (u32 i = tid; i < lowLimit; i += kTile) L.in[i] = 0;
+    } else {
     if (kPrefetch && pfValid) {                            // (uniform) a full aligned chunk, already in registers
         uint4* l4 = reinterpret_cast<uint4*>(L.in);
         l4[tid] = pf0; l4[tid + kTile] = pf1; l4[tid + 2 * kTile] = pf2; l4[tid + 3 * kTile] = pf3;
@@ -646,13 +835,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     } else {
         for (u32 i = tid; i < nData; i += kTile) L.in[hist + i] = in[i];
     }
-    if (DICT) {
-        if (frameBlocks && ((((uintptr_t)prefix) | lowLimit) & 15) == 0) {                  // the input in front of the block: 16 bytes per lane
-            const uint4* p4 = reinterpret_cast<const uint4*>(prefix);
-            uint4* l4 = reinterpret_cast<uint4*>(L.in + lowLimit);
-            for (u32 i = tid; i < (prefixLen >> 4); i += kTile) l4[i] = p4[i];
-            for (u32 i = tid; i < lowLimit; i += kTile) L.in[i] = 0;
-        } else for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
+    if (DICT) for (u32 i = tid; i < hist; i += kTile) L.in[i] = i >= lowLimit ? prefix[i - lowLimit] : (u8)0;
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
     u32* const endOf = reinterpret_cast<u32*>(L.jumpB);
@@ -770,6 +953,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
     // history / dictionary tiles (those wholly below lowLimit are padding) only fill the tables: searched, never parsed
     if (DICT && lowLimit < hist) insert_tiles<MODE>(L, n, lowLimit >> kTileLog, hist >> kTileLog, 0xFFFFFFFFu, lowLimit, nullptr, tid);
+    ZMI_STAMP(8);                        // (dense-tile select shares the slot: told apart by the workload)
     for (u32 t = hist >> kTileLog, it = 0; t < nTiles; ++it) {
         const u32 tileStart = t * kTilePos;
         // stride: every 2nd / 4th position after a sparse tile; where a strided iteration found next to nothing either, every
@@ -1242,10 +1426,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // loop verifies every position to keep one in eight.  (A kernel of its own: with the region parse inlined here the tile
         // loop itself ran 8 % slower on sparse data — code size.)
         if (!FAR && regionList && tileStart == hist && !super && strideLog == 0 && matchCount >= kDenseMin && nTiles > (hist >> kTileLog) + 2) {      // uniform
-            if (MODE == 0 && !DICT) { regionCursor = cursor + 1; break; }
-            __syncthreads();
-            dense_rest<MODE>(L, n, t, t, nTiles, hist, lowLimit, candAll + (u64)c * kChunkSize, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
-            break;
+            if constexpr ((MODE == 0 && !DICT) || MODE == 2) { regionCursor = cursor + 1; break; }     // (kSplit of launch_one)
+            else {
+                __syncthreads();
+                dense_rest<MODE>(L, n, t, t, nTiles, hist, lowLimit, candAll + (u64)c * kChunkSize, nullptr, 0, seqOut, litOut, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+                break;
+            }
         }
     }
 #ifdef ZMI_LZ_STAMPS
@@ -1268,11 +1454,16 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     }
 }
 
-// The rest of a dense chunk for the fast finder on plain chunks (see dense_rest): the chunk is staged again, the table gets the
-// first tile's positions (the latest occurrence per bucket, as the tile loop left it; the first-occurrence table starts empty: it
-// only ever serves the tile that filled it), and the region parse takes tiles 1 .. from the state lz_kernel recorded.
+// The rest of a dense chunk (see dense_rest) as a kernel of its own — the fast finder on plain chunks (with the region parse
+// inlined its tile loop ran 8 % slower on sparse data: code size) and the level >= 5 finder (whose hash-chain search wants the
+// registers the tile loop's state would occupy: inlined, it spilled 288 bytes per lane): the chunk, and the history or dictionary
+// tail in front of it, is staged again; the fast finder's table gets the first tile's positions (the latest occurrence per
+// bucket, as the tile loop left it; the first-occurrence table starts empty: it only ever serves the tile that filled it); and
+// the region parse takes the tiles after the first from the state lz_kernel recorded.
+template <int MODE, bool DICT>
 __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ src, u64 srcSize, Seq* __restrict__ seqs, u8* __restrict__ lits,
-                                                         ChunkMeta* __restrict__ meta, u16* __restrict__ candAll, const u32* __restrict__ regionList)
+                                                         ChunkMeta* __restrict__ meta, u16* __restrict__ candAll, u16* __restrict__ chainAll, const u32* __restrict__ regionList,
+                                                         const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes, const u32 frameBlocks, const u32 hcDepth)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -1282,43 +1473,63 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
     for (u32 li = blockIdx.x; li < count; li += gridDim.x) {
     const u32 c = regionList[1 + li];
     const u32 rc = meta[c].regionCursor;
-    const u64 base = (u64)c * kChunkSize;
+    // geometry as in lz_kernel
+    const u32 cb = DICT ? chunkBytes : kChunkSize;
+    const u32 hist = DICT ? kChunkSize - chunkBytes : 0u;
+    const u64 base = (u64)c * cb;
     const u8* __restrict__ in = src + base;
-    const u32 n = (u32)((srcSize - base) < kChunkSize ? (srcSize - base) : kChunkSize);
-    if ((((uintptr_t)in) & 15) == 0) {
-        const uint4* in4 = reinterpret_cast<const uint4*>(in);
-        uint4* l4 = reinterpret_cast<uint4*>(L.in);
-        const u32 full = n >> 4;
-        uint4 v0, v1, v2, v3;
-        const u32 i0 = tid, i1 = tid + kTile, i2 = tid + 2 * kTile, i3 = tid + 3 * kTile;
-        v0 = in4[i0 < full ? i0 : 0]; v1 = in4[i1 < full ? i1 : 0]; v2 = in4[i2 < full ? i2 : 0]; v3 = in4[i3 < full ? i3 : 0];
-        if (i0 < full) l4[i0] = v0;
-        if (i1 < full) l4[i1] = v1;
-        if (i2 < full) l4[i2] = v2;
-        if (i3 < full) l4[i3] = v3;
-        for (u32 i = (full << 4) + tid; i < n; i += kTile) L.in[i] = in[i];
-    } else {
-        for (u32 i = tid; i < n; i += kTile) L.in[i] = in[i];
+    const u32 bf = (DICT && frameBlocks) ? c % frameBlocks : 0u;
+    u32 prefixLen = prefixLenArg; const u8* __restrict__ prefix = prefixArg;
+    if (DICT && frameBlocks) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
+    const u32 lowLimit = DICT ? hist - prefixLen : 0u;
+    const u32 nData = (u32)((srcSize - base) < cb ? (srcSize - base) : cb);
+    const u32 n = hist + nData;
+    {   // the image [lowLimit, n): history (or dictionary tail) + block.  Cross-chunk history is one contiguous piece of the input
+        const bool onePiece = !DICT || frameBlocks != 0;
+        const u8* __restrict__ from = onePiece ? in - prefixLen : in;
+        const u32 at = onePiece ? lowLimit : hist, bytes = onePiece ? prefixLen + nData : nData;
+        if ((((uintptr_t)from) | at) % 16 == 0) {
+            const uint4* in4 = reinterpret_cast<const uint4*>(from);
+            uint4* l4 = reinterpret_cast<uint4*>(L.in + at);
+            const u32 full = bytes >> 4;
+            uint4 v0, v1, v2, v3;
+            const u32 i0 = tid, i1 = tid + kTile, i2 = tid + 2 * kTile, i3 = tid + 3 * kTile;
+            v0 = in4[i0 < full ? i0 : 0]; v1 = in4[i1 < full ? i1 : 0]; v2 = in4[i2 < full ? i2 : 0]; v3 = in4[i3 < full ? i3 : 0];
+            if (i0 < full) l4[i0] = v0;
+            if (i1 < full) l4[i1] = v1;
+            if (i2 < full) l4[i2] = v2;
+            if (i3 < full) l4[i3] = v3;
+            for (u32 i = (full << 4) + tid; i < bytes; i += kTile) L.in[at + i] = from[i];
+        } else {
+            for (u32 i = tid; i < bytes; i += kTile) L.in[at + i] = from[i];
+        }
+        if (DICT && !onePiece) for (u32 i = lowLimit + tid; i < hist; i += kTile) L.in[i] = prefix[i - lowLimit];
+        for (u32 i = tid; i < lowLimit; i += kTile) L.in[i] = 0;
     }
     for (u32 i = n + tid; i < kChunkSize + kInPad; i += kTile) L.in[i] = 0;
-    u32* const table = L.tabMem;
-    {
+    {   // tables as lz_kernel starts them (the level >= 5 search lays its own over them)
         uint4* const t4 = reinterpret_cast<uint4*>(L.tabMem);
         const uint4 z = {0u, 0u, 0u, 0u}, f = {~0u, ~0u, ~0u, ~0u};
 #pragma unroll
-        for (u32 k = 0; k < 2; ++k) { t4[tid + k * kTile] = z; t4[2 * kTile + tid + k * kTile] = f; }
+        for (u32 k = 0; k < 2; ++k) { t4[tid + k * kTile] = MODE == 0 ? z : f; t4[2 * kTile + tid + k * kTile] = MODE == 0 ? f : z; }
     }
     __syncthreads();
+    u32 insertFrom = lowLimit >> kTileLog;
+    if (MODE == 0 && !DICT) {                              // the first tile's positions into the table
+        u32* const table = L.tabMem;
 #pragma unroll
-    for (u32 j = 0; j < kPPT; ++j) {                       // the first tile's positions into the table
-        const u32 p = j * kTile + tid;
-        if (p + 8 <= n) { const u32 hp = hash6p(lds_load8(L.in, p)); atomicMax(&table[hidx(hp)], ((p + 1) << 16) | htag(hp)); }
+        for (u32 j = 0; j < kPPT; ++j) {
+            const u32 p = j * kTile + tid;
+            if (p + 8 <= n) { const u32 hp = hash6p(lds_load8(L.in, p)); atomicMax(&table[hidx(hp)], ((p + 1) << 16) | htag(hp)); }
+        }
+        __syncthreads();
+        insertFrom = 1;
     }
-    __syncthreads();
     const ChunkMeta m0 = meta[c];
     u32 cursor = rc - 1, nbSeq = m0.nbSeq, litBase = m0.litSize; bool deferred = m0.litFromSrc != 0;
     const u32 nTiles = (n + kTilePos - 1) / kTilePos;
-    dense_rest<0>(L, n, 1, 1, nTiles, 0, 0, candAll + (u64)c * kChunkSize, seqs + (u64)c * kMaxSeq, lits + (u64)c * kLitStride, cursor, nbSeq, litBase, deferred, tid, lane, wave);
+    dense_rest<MODE>(L, n, insertFrom, (hist >> kTileLog) + 1, nTiles, hist, lowLimit, candAll + (u64)c * kChunkSize, chainAll ? chainAll + (u64)c * kChunkSize : nullptr, hcDepth,
+                     seqs + (u64)c * kMaxSeq, lits + (u64)c * kLitStride, cursor, nbSeq, litBase, deferred, tid, lane, wave);
     if (tid == 0) { meta[c].nbSeq = nbSeq; meta[c].litSize = litBase; meta[c].litFromSrc = deferred ? 1u : 0u; }
     __syncthreads();                                       // the next chunk takes over LDS
     }
@@ -1336,17 +1547,16 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream)
 {
-    // the region parse of dense chunks: a second kernel behind a work list for the fast finder on plain chunks (with that code inlined
-    // its tile loop ran 8 % slower on sparse data — code size — and BASELINE's headline is sparse data at level 1), inlined otherwise
-    constexpr bool kSplit = MODE == 0 && !DICT && !FAR;
+    // the region parse of dense chunks: a second kernel behind a work list (see lz_region_kernel), inlined for the others
+    constexpr bool kSplit = (MODE == 0 && !DICT && !FAR) || MODE == 2;
     // (the attribute is per device: a process may hold contexts on several GPUs)
     static bool attrSet[64] = {};
     int dev = 0; (void)hipGetDevice(&dev);
     if (!attrSet[dev & 63]) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_kernel<MODE, SHORT, DICT, FAR>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
-        if (kSplit) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_region_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
+        if constexpr (kSplit) (void)hipFuncSetAttribute(reinterpret_cast<const void*>(lz_region_kernel<MODE, DICT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(LzLds));
         attrSet[dev & 63] = true;
     }
     if (FAR) cand = nullptr;
@@ -1354,9 +1564,10 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
     // (the fast finder on plain chunks: 4096 workgroups — 1024 balanced mixed data visibly worse —, each takes every 4096th chunk with the next one's bytes in flight; the hardware
     //  still hands workgroups to CUs as they free up, which is what balances chunks of unequal cost.  Everything else: a workgroup per chunk)
     const u32 grid = (MODE == 0 && !DICT && !FAR && nChunks > 4096) ? 4096u : nChunks;
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, cand ? regionList : nullptr, nChunks);
-    if (kSplit && cand)                                    // the dense chunks' rest: 256 workgroups (one per CU) walk the list
-        hipLaunchKernelGGL(lz_region_kernel, dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, regionList);
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, cand ? chain : nullptr, cand ? regionList : nullptr, nChunks);
+    if constexpr (kSplit) if (cand)                        // the dense chunks' rest: 256 workgroups (one per CU) walk the list
+        hipLaunchKernelGGL((lz_region_kernel<MODE, DICT>), dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, chain, regionList,
+                           prefix, prefixLen, chunkBytes, frameBlocks, hcDepth);
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
@@ -1366,24 +1577,24 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.
 // cand / regionList (null: off): workspace of the region parse, 65536 u16 per chunk and 1 + nChunks u32.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream)
 {
     if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
-        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, stream);
+        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, nullptr, 0, stream);
         return;
     }
     if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, regionList, stream); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, regionList, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, regionList, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, regionList, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, regionList, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, regionList, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream); break;
     }
 }
 

@@ -18,7 +18,7 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u32* regionList, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
@@ -127,6 +127,7 @@ struct ZSTD_CCtx_s {
     // above; and whenever the caller asks for a windowLog above 16), 0 = off (independent 64 KiB frames), else the bytes of
     // history per block (4 KiB units)
     int historyBytes = -1; u32 frameBytes = 256u << 10;
+    u32 parser = 0;                      // ZSTDMI_CCtx_setParser
     // streaming adapter (ZSTD_compressStream2): host-side batching in front of the one-shot engine
     std::vector<u8> sIn, sOut; size_t sOutPos = 0; bool sWrote = false, sEnding = false; size_t sBatch = (size_t)16 << 20;
     StageTimer timer;
@@ -199,13 +200,13 @@ static size_t dctx_bind(ZSTD_DCtx* d)
 // ZSTD_compressCCtx, the level alone with default frame parameters and no dictionary (U/ZstdCompress.cs:5751-5776:
 // compress_usingDict(NULL) builds its parameters from the level and leaves the context's requested ones untouched).
 struct CallParams {
-    int level = 3, checksumFlag = 0, dictIDFlag = 1, strategy = 0, targetLength = 0, windowLog = 0;
+    int level = 3, checksumFlag = 0, dictIDFlag = 1, strategy = 0, targetLength = 0, windowLog = 0, searchLog = 0;
     bool useDict = true;
 };
 static CallParams sticky_params(const ZSTD_CCtx* c)
 {
     CallParams p; p.level = c->level; p.checksumFlag = c->checksumFlag; p.dictIDFlag = c->dictIDFlag;
-    p.strategy = c->strategy; p.targetLength = c->targetLength; p.windowLog = c->windowLog; p.useDict = true;
+    p.strategy = c->strategy; p.targetLength = c->targetLength; p.windowLog = c->windowLog; p.searchLog = c->searchLog; p.useDict = true;
     return p;
 }
 
@@ -218,6 +219,7 @@ static Resolved resolve_call(const CallParams& p, size_t srcSize, u32 chunkBytes
     r.cp = get_cparams(p.level, srcSize < chunkBytes ? srcSize : chunkBytes);
     if (p.strategy) r.cp.strategy = (u32)p.strategy;
     if (p.targetLength) r.cp.targetLength = (u32)p.targetLength;
+    if (p.searchLog) r.cp.searchLog = (u32)p.searchLog;
     // match finder by strategy (U/ZstdCompress.cs:3397-3417 selects the block compressor the same way): fast; doubleFast -> the
     // dual-hash finder; greedy and everything above it -> dual-hash + lazy deferral (no lazy2 / binary-tree / optimal parsers)
     r.finder = r.cp.strategy <= kStratFast ? 0u : r.cp.strategy == kStratDfast ? 1u : 2u;
@@ -242,7 +244,9 @@ static bool cctx_workspace(ZSTD_CCtx* c, u32 nChunks)
            c->total.ensure(64);
 }
 // the region parse of the fast strategy keeps one candidate position (u16) per input byte between its two steps (lz_fast.hip)
-static bool cctx_cand_workspace(ZSTD_CCtx* c, u32 nChunks) { return c->cand.ensure((size_t)nChunks * kChunkSize * sizeof(u16) + 256 + ((size_t)nChunks + 1) * sizeof(u32)); }
+// region parse: candidates (u16 per position of a chunk's 64 KiB image) [+ the hash chains of the level >= 5 finder, same size] + the work list
+static size_t cand_plane_bytes(u32 nChunks) { return (size_t)nChunks * kChunkSize * sizeof(u16) + 256; }
+static bool cctx_cand_workspace(ZSTD_CCtx* c, u32 nChunks, bool chains) { return c->cand.ensure(cand_plane_bytes(nChunks) * (chains ? 2 : 1) + ((size_t)nChunks + 1) * sizeof(u32)); }
 
 // upload a newly loaded dictionary; a formatted one is first validated on the device (ZSTD_loadCEntropy's checks are those of
 // ZSTD_loadDEntropy plus the symbol-coverage rules that only matter to an encoder reusing the tables) -> dictionary_corrupted
@@ -322,8 +326,14 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
     u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
     if (frameBlocks && passChunks < totalChunks) { passChunks -= passChunks % frameBlocks; if (!passChunks) passChunks = frameBlocks; }     // frames never straddle passes
     if (!cctx_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
-    const bool regionParse = rs.minStrideLog == 0 && !(rs.finder == 0 && frameBlocks && chunkBytes >= kChunkSize) && !getenv("ZSTDMI_NO_REGION");   // (not the far-candidate finder)
-    if (regionParse && !cctx_cand_workspace(c, passChunks)) return ZERR(kErrMemoryAllocation);
+    const bool regionParse = rs.minStrideLog == 0 && !(rs.finder == 0 && frameBlocks && chunkBytes >= kChunkSize) && c->parser == 0;   // (not the far-candidate finder)
+    const bool hcChains = regionParse && rs.finder >= 2;
+    // attempts per position of the level >= 5 search: the reference's 1 << searchLog (U/ZstdLazy.cs:641-642), between 4 and 32; the
+    // greedy and lazy strategies (levels 5-7) stop at 8 unless ZSTD_c_searchLog asks for more: measured on text, 32 attempts
+    // instead of 8 cost twice the time for 1 % of size
+    u32 hcDepth = rs.cp.searchLog < 2 ? 4u : rs.cp.searchLog > 5 ? 32u : 1u << rs.cp.searchLog;
+    if (hcDepth > 8 && rs.cp.strategy <= 4 && cp.searchLog == 0) hcDepth = 8;
+    if (regionParse && !cctx_cand_workspace(c, passChunks, hcChains)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy;      // ZSTD_selectEncodingType's < lazy heuristic is the one seq_encode holds (U/ZstdCompressSequences.cs:400-469): levels whose strategy is lazy or above get greedy's constants
     size_t produced = 0;
     bool first = true;
@@ -334,7 +344,8 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, regionParse ? (u32*)((u8*)c->cand.p + (size_t)passChunks * kChunkSize * sizeof(u16) + 256) : nullptr, s);      c->timer.mark("lz_fast", s);
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, hcChains ? (u16*)((u8*)c->cand.p + cand_plane_bytes(passChunks)) : nullptr,
+                  regionParse ? (u32*)((u8*)c->cand.p + cand_plane_bytes(passChunks) * (hcChains ? 2 : 1)) : nullptr, hcDepth, s);      c->timer.mark("lz_fast", s);
         launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s);        c->timer.mark("huf_build", s);
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
@@ -416,11 +427,14 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
         const CParams cp = get_cparams(c->level, kChunkSize);
         if (value != 0 && value != (int)kernel_min_match(c->strategy ? (u32)c->strategy : cp.strategy)) return ZERR(kErrParameterUnsupported);
         c->minMatch = value; return (size_t)value; }
-    case ZSTD_c_chainLog: case ZSTD_c_searchLog: {   // no chain and no search depth in the tile finders: only the level's own value is accepted
-        if (value != 0 && (value < (param == ZSTD_c_chainLog ? 6 : 1) || value > 30)) return ZERR(kErrParameterOutOfBound);
+    case ZSTD_c_chainLog: {      // the chain table covers the finder's whole 64 KiB window: only the level's own value is accepted
+        if (value != 0 && (value < 6 || value > 30)) return ZERR(kErrParameterOutOfBound);
         const CParams cp = get_cparams(c->level, kChunkSize);
-        if (value != 0 && value != (int)(param == ZSTD_c_chainLog ? cp.chainLog : cp.searchLog)) return ZERR(kErrParameterUnsupported);
-        (param == ZSTD_c_chainLog ? c->chainLog : c->searchLog) = value; return (size_t)value; }
+        if (value != 0 && value != (int)cp.chainLog) return ZERR(kErrParameterUnsupported);
+        c->chainLog = value; return (size_t)value; }
+    case ZSTD_c_searchLog:       // attempts per position of the greedy/lazy search = 1 << searchLog (used from 2 to 5: 4 .. 32 attempts)
+        if (value != 0 && (value < 1 || value > 30)) return ZERR(kErrParameterOutOfBound);
+        c->searchLog = value; return (size_t)value;
     default: return ZERR(kErrParameterUnsupported);
     }
 }
@@ -985,6 +999,7 @@ size_t ZSTDMI_CCtx_setHistory(ZSTD_CCtx* c, int bytes, unsigned frameBytes)
     if (!c || bytes > (48 << 10) || (frameBytes && (frameBytes < kChunkSize || frameBytes > (16u << 20)))) return ZERR(kErrParameterOutOfBound);
     c->historyBytes = bytes; if (frameBytes) c->frameBytes = frameBytes; return 0;
 }
+size_t ZSTDMI_CCtx_setParser(ZSTD_CCtx* c, unsigned mode) { if (!c || mode > 1) return ZERR(kErrParameterOutOfBound); c->parser = mode; return 0; }
 size_t ZSTDMI_CCtx_setProfiling(ZSTD_CCtx* c, int en) { if (!c) return ZERR(kErrGeneric); c->timer.enabled = en != 0; return 0; }
 size_t ZSTDMI_DCtx_setProfiling(ZSTD_DCtx* d, int en) { if (!d) return ZERR(kErrGeneric); d->timer.enabled = en != 0; return 0; }
 int ZSTDMI_CCtx_getStageTimes(const ZSTD_CCtx* c, float* ms, const char** names, int cap)
