@@ -21,7 +21,7 @@ for kind in ("zipf", "text"):
     cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
-    buf = (ctypes.c_ulonglong * 16)(); raw.ZSTDMI_debugReadLzStamps(buf, 1); raw.ZSTDMI_debugReadHufStamps(buf, 1); raw.ZSTDMI_debugReadSeqEncStamps(buf, 1)
+    buf = (ctypes.c_ulonglong * 24)(); raw.ZSTDMI_debugReadLzStamps(buf, 1); raw.ZSTDMI_debugReadHufStamps(buf, 1); raw.ZSTDMI_debugReadSeqEncStamps(buf, 1)
     lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
     raw.ZSTDMI_debugReadLzStamps(buf, 1)
     tot = sum(buf[i] for i in range(16)); chunks = n // 65536

@@ -19,8 +19,10 @@ host = np.tile(datagen.text_like(32 << 20, 7), 8)[:n] if kind == "text" else np.
 src = torch.from_numpy(host.copy()).cuda(); torch.cuda.synchronize()
 cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, level); lib.ZSTDMI_CCtx_setProfiling(c, 1)
+sl = int(os.environ.get("SEARCHLOG", "0"))
+if sl: assert lib.ZSTD_CCtx_setParameter(c, 104, sl) == sl
 for _ in range(3): cs = lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.data_ptr(), n)
 ms = (ctypes.c_float * 16)(); names = (ctypes.c_char_p * 16)()
 k = lib.ZSTDMI_CCtx_getStageTimes(c, ms, names, 16)
 st = {names[i].decode(): ms[i] for i in range(k)}
-print(f"{libs[0]:40s} level {level} {kind}: lz {st.get('lz_fast', 0) * 4:.2f} ms/GiB  ratio {cs / n:.5f}", flush=True)
+print(f"{libs[0]:40s} searchLog {sl} level {level} {kind}: lz {st.get('lz_fast', 0) * 4:.2f} ms/GiB  ratio {cs / n:.5f}", flush=True)

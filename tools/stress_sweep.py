@@ -20,7 +20,7 @@ def main():
     t0 = time.time(); n_cases = 0
     comps = {}; decs = {}
     while time.time() - t0 < budget:
-        kind = rng.choice(kinds); level = rng.choice([1, 1, 3, 5]); chk = rng.randrange(2); dk = rng.choice(list(dicts))
+        kind = rng.choice(kinds); level = rng.choice([1, 1, 3, 5, 5, 7, 9]); chk = rng.randrange(2); dk = rng.choice(list(dicts))
         n = rng.choice([rng.randrange(0, 300), rng.randrange(0, 70000), rng.randrange(0, 400000), 65536 * rng.randrange(1, 5) + rng.randrange(-2, 3),
                         32768 * rng.randrange(1, 40) + rng.randrange(-2, 3)])
         data = datagen.gen(kind, n, rng.randrange(1 << 30))

@@ -34,7 +34,7 @@ namespace zmi {
 
 #ifdef ZMI_LZ_STAMPS
 // diagnostic build only (make STAMPS=1): per-phase shader-clock sums of thread 0 of every workgroup
-__device__ unsigned long long g_lzStamps[16];
+__device__ unsigned long long g_lzStamps[24];     // 0-9 tile loop, 10-15 region parse, 16-23 hash-chain search (level >= 5)
 #define ZMI_STAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); stampAcc[i] += now_ - stampLast; stampLast = now_; } } while (0)
 // (the region parse is a function of its own: it times itself from its entry and adds to the global sums directly)
 #define ZMI_DSTAMP(i) do { if ((tid & 63u) == 0) { const unsigned long long now_ = __builtin_amdgcn_s_memtime(); dAcc[(i) - 10] += now_ - dLast; dLast = now_; } } while (0)
@@ -378,8 +378,9 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             }
             *reinterpret_cast<u64*>(&Hc.hashes[q0]) = h4;
         }
-        ZMI_DSTAMP(10);
+        ZMI_DSTAMP(16);
         lds_barrier();
+        ZMI_DSTAMP(17);
         // ---- links: one wave, group after group (see above); four groups' reads and updates per step ----
         if (wave == 0) {                                   // eight groups per step, the next step's hashes already on their way
             u32 hn[8];
@@ -403,8 +404,9 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
                 for (u32 k = 0; k < 8; ++k) tilePred[(g + k) * 64 + lane] = (u16)(val[k] ? pv[k] : 0u);
             }
         }
+        ZMI_DSTAMP(18);
         lds_barrier();
-        ZMI_DSTAMP(11);
+        ZMI_DSTAMP(19);
         if (tid < 512) reinterpret_cast<uint4*>(chainG + tileStart)[tid] = reinterpret_cast<const uint4*>(tilePred)[tid];
         // ---- search ----
         if (t >= candFrom) {                               // uniform
@@ -472,11 +474,13 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             for (u32 j = 0; j < 4; ++j) out4 |= (u64)(best[j] & 0xFFFFu) << (16 * j);
             if (p0 < n) *reinterpret_cast<u64*>(candG + p0) = out4;
         }
+        ZMI_DSTAMP(20);
         lds_barrier();                                     // (the search is done with the ring slot this tile takes over)
+        ZMI_DSTAMP(21);
         if (tid < 512) reinterpret_cast<uint4*>(ring + (t % kRing) * kTilePos)[tid] = reinterpret_cast<const uint4*>(tilePred)[tid];
         // the links in global memory are read by tiles at least kRing + 1 after this one: every kRing-th tile waits for the stores
         if (t % kRing == kRing - 1) __syncthreads(); else lds_barrier();
-        ZMI_DSTAMP(13);
+        ZMI_DSTAMP(22);
     }
 }
 
@@ -496,7 +500,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
     static_assert(offsetof(LzLds, tileLen) + sizeof(DenseLds) + kMaxPassSeq * sizeof(u16) <= sizeof(LzLds), "rank list must fit behind DenseLds");
     u16* const rankPos = reinterpret_cast<u16*>(reinterpret_cast<u8*>(&D) + sizeof(DenseLds));
 #ifdef ZMI_LZ_STAMPS
-    unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
     // ---------------- I: candidates of every position, tile by tile ----------------
     if constexpr (MODE == 2) hc_tiles(L, n, lowLimit >> kTileLog, nTiles, fromTile, lowLimit, hcDepth, candG, chainG, tid, lane, wave
@@ -750,7 +754,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
         cursor = totE; nbSeq += totM; litBase += totK;
     }
 #ifdef ZMI_LZ_STAMPS
-    if ((tid & 63u) == 0) for (int i = 0; i < 6; i++) atomicAdd(&g_lzStamps[10 + i], dAcc[i]);
+    if ((tid & 63u) == 0) for (int i = 0; i < 14; i++) atomicAdd(&g_lzStamps[10 + i], dAcc[i]);
 #endif
 }
 
@@ -1540,8 +1544,8 @@ size_t lz_fast_lds_bytes() { return sizeof(LzLds); }
 #ifdef ZMI_LZ_STAMPS
 extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 {
-    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lzStamps), 16 * sizeof(unsigned long long));
-    if (reset) { unsigned long long z[16] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzStamps), z, sizeof z); }
+    (void)hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_lzStamps), 24 * sizeof(unsigned long long));      // (24 entries)
+    if (reset) { unsigned long long z[24] = {}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_lzStamps), z, sizeof z); }
 }
 #endif
 
