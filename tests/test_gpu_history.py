@@ -180,3 +180,23 @@ def test_region_parse_and_tile_loop_both_restore_the_input_and_never_lose_more_t
         assert gpu_lib.ZSTDMI_CCtx_setParser(c.cctx, 2) != 0
     # (level >= 5: the region parse searches hash chains eight deep, the tile loop knows four candidates: it may only be smaller)
     assert sizes[0] <= 1.01 * sizes[1] and (level >= 5 or sizes[1] <= 1.01 * sizes[0]), sizes
+
+
+def test_level5_and_9_search_deeper_and_stay_near_the_oracle_at_the_same_frame_size(gpu_lib, oracle):
+    """Levels >= 5 (greedy / lazy behind a chain search, U/ZstdLazy.cs:619-760, 1743-2032): 1 << searchLog attempts per position —
+    8 at levels 5-7, 32 at level 9 on 256 KiB frames (U/Clevels.cs:243-474), or what ZSTD_c_searchLog asks for.  More attempts
+    never lose; the distance to the oracle's own level 5 at the same frame size is what the 64 KiB window costs."""
+    data = datagen.gen("text", 2 << 20, 4)
+    sizes = {}
+    for level in (3, 5, 9):
+        with z.Compressor(level) as c:
+            comp = c.Wrap(data)
+            assert oracle.decompress(comp, len(data)) == data
+            sizes[level] = len(comp)
+    with z.Compressor(5) as c:
+        c.SetParameter(104, 5)                                   # ZSTD_c_searchLog
+        sizes["5+sl5"] = len(c.Wrap(data))
+    ref = len(oracle.compress(data, 5, 0, 256 << 10))
+    print("level sizes", sizes, "oracle level 5, 256 KiB frames", ref, {k: round(v / ref, 4) for k, v in sizes.items()})
+    assert sizes[5] <= 0.97 * sizes[3] and sizes[9] <= sizes[5] and sizes["5+sl5"] <= sizes[5]
+    assert sizes[5] <= 1.09 * ref and sizes[9] <= 1.08 * ref, (sizes, ref)       # measured 1.069 / 1.058 (+ 2 %)

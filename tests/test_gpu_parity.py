@@ -367,7 +367,9 @@ def test_levels_buy_ratio(gpu_lib, oracle):
         assert sizes[(kind, 3)] <= sizes[(kind, 1)] * 1.005, (kind, sizes)
         assert sizes[(kind, 5)] <= sizes[(kind, 3)] * 1.005, (kind, sizes)
         assert sizes[(kind, 7)] <= sizes[(kind, 5)] * 1.005, (kind, sizes)
-        for level, slack in ((3, 1.055), (5, 1.035)):        # measured (round 2): text 1.0328 / 1.0136, mixed 1.0108 / 0.9940, + 2 %
+        if kind == "text":     # level 5 earns its level: the hash-chain search (8 attempts) against the dual-hash finder of level 3
+            assert sizes[(kind, 5)] <= sizes[(kind, 3)] * 0.97, (kind, sizes)
+        for level, slack in ((3, 1.035), (5, 1.0)):          # measured (round 2): text 1.0143 / 0.9398, mixed 1.0134 / 0.9758 (+ 2 %; level 5: never above)
             ref = len(oracle.compress(data, level, 0, 65536))
             print(f"ratio-vs-oracle L{level} {kind}: gpu {sizes[(kind, level)]} ref {ref} = {sizes[(kind, level)] / ref:.4f}")
             assert sizes[(kind, level)] <= ref * slack + 64, (kind, level, sizes[(kind, level)], ref)
