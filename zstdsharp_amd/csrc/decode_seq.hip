@@ -330,6 +330,8 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
             // ---- phase B: 64 steps of every chain.  Per sequence a lane reads its three table entries (LDS) and, independently of
             // them, the 128 stream bits below its bit position (global memory; a stream is walked downward, so these loads stay in
             // one cache line for a dozen sequences); the extra-bit fields are only skipped here ----
+            // (this wave's dependent chain competes for issue slots with the helper waves of the workgroups sharing its SIMD: it goes first)
+            __builtin_amdgcn_s_setprio(3);
             if (base < mNbSeq) {
                 const u32 steps = mNbSeq - base < 64 ? mNbSeq - base : 64, buf = bt & 1;
                 const s32 ringLo = L.ringLo[buf][lane], pos0 = pos;
@@ -338,15 +340,13 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
                 for (u32 k = 0; k < steps; ++k) {
                     const u32 eLL = mT[kTabLL + sLL], eML = mT[kTabML + sML], eOF = mT[kTabOF + sOF];
                     const s32 dl = ((pos - 1) >> 5) - 3;                // the window: stream dwords dl .. dl + 3, at least bits [pos - 97, pos)
-                    u32 w0, w1, w2, w3;
-                    if (4 * dl >= ringLo) {                             // staged (always, unless a damaged stream runs away below its start)
-                        const u32 ix0 = (u32)dl & (kRingDw - 1);
-                        w0 = R[ix0]; w1 = R[(ix0 + 1) & (kRingDw - 1)]; w2 = R[(ix0 + 2) & (kRingDw - 1)]; w3 = R[(ix0 + 3) & (kRingDw - 1)];
-                    } else
-                    if (dl >= 0 && 4 * dl + 16 <= mSize) {
-                        const u64 a = readLE64(mSp + 4 * dl), b = readLE64(mSp + 4 * dl + 8);
-                        w0 = (u32)a; w1 = (u32)(a >> 32); w2 = (u32)b; w3 = (u32)(b >> 32);
-                    } else { w0 = stream_dword_z(mSp, mSize, dl); w1 = stream_dword_z(mSp, mSize, dl + 1); w2 = stream_dword_z(mSp, mSize, dl + 2); w3 = stream_dword_z(mSp, mSize, dl + 3); }
+                    // the window comes out of the ring.  (Staged, always: a valid stream never reaches more than 16 bytes below its
+                    // start, and the ring is staged down to 64 below.  A damaged stream that runs away further reads the lowest staged
+                    // dwords instead — in bounds, wrong bits, states stay inside their tables by construction; the fields phase sees
+                    // the negative positions and reports corruption, as it did when this case read zeros.)
+                    const s32 dlc = 4 * dl >= ringLo ? dl : (ringLo >> 2);
+                    const u32 ix0 = (u32)dlc & (kRingDw - 1);
+                    const u32 w0 = R[ix0], w1 = R[(ix0 + 1) & (kRingDw - 1)], w2 = R[(ix0 + 2) & (kRingDw - 1)], w3 = R[(ix0 + 3) & (kRingDw - 1)];
                     L.recSt[buf][lane][k] = sLL | (sML << 10) | (sOF << 20); L.recPos[buf][lane][k] = (u16)(pos0 - pos);
                     const u32 nLL = (eLL >> 16) & 15u, nML = (eML >> 16) & 15u, nOF = (eOF >> 16) & 15u, nbTot = nLL + nML + nOF;
                     const s32 q = pos - (s32)(((eLL >> 20) & 31u) + ((eML >> 20) & 31u) + ((eOF >> 20) & 31u)) - (s32)nbTot;
@@ -360,6 +360,7 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
                     pos = q;
                 }
             }
+            __builtin_amdgcn_s_setprio(0);
             if (lane < kPack) L.curByte[(bt + 1) & 1][lane] = pos >> 3;
         } else {
             // ---- phase C for the previous 64 sequences of this wave's blocks ----

@@ -320,6 +320,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
             __syncthreads();
             ZMI_ESTAMP(3);
             if (done < chainSeq) {
+                __builtin_amdgcn_s_setprio(3);          // the serial chains go ahead of the wave-parallel work sharing their SIMD
                 // a chain step is: nb = (state + deltaNbBits) >> 16, emit the low nb bits, state = table[(state >> nb) + deltaFindState]
                 // (FSE_encodeSymbol, U/Fse.cs:41-49); the transforms come four at a time, ahead of the states that need them
                 const u32 ccnt = chainSeq - done < 64 ? chainSeq - done : 64;
@@ -352,6 +353,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
                         state = stT[(s32)(state >> nb) + t3.deltaFindState];
                     }
                 }
+                __builtin_amdgcn_s_setprio(0);
             }
             __syncthreads();
             ZMI_ESTAMP(4);
