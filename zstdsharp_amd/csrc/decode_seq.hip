@@ -44,7 +44,7 @@ constexpr u32 kRing = 2048, kRingDw = kRing / 4;
 constexpr u32 kTabLL = 0, kTabML = 512, kTabOF = 1024, kTabWords = 1280;
 
 struct SeqLds {
-    u32 tab[kPack][kTabWords];           // one entry per state: nextState:16 | nbBits:4 (bit 16) | nbAddBits:5 (bit 20) | symbol:6 (bit 25)
+    u32 tab[kPack][kTabWords];           // one entry per state: nextState:16 | nbBits:4 (bit 16) | nbBits + nbAddBits:6 (bit 20: what a step consumes) | symbol:6 (bit 26)
     u32 recSt[2][kPack][64];             // phase B -> C (double-buffered): the three states before each of a block's 64 sequences ...
     u16 recPos[2][kPack][64];            // ... and the bit position, as posBase - position
     s32 posBase[2][kPack];               // bit position at the start of the batch
@@ -52,7 +52,7 @@ struct SeqLds {
     // staged byte the chain may rely on in a batch, curByte = byte the chain stands at when a batch starts (both double-buffered:
     // written during one batch for the next)
     union {
-        u32 ring[kPack][kRingDw];
+        u32 ring[kPack][kRingDw + 4];     // (+ the first three dwords again behind the end: a window of four never wraps)
         struct { s16 norm[4][64]; u16 symbolNext[4][64]; } build;     // table-build scratch, one per wave (phase A only)
     };
     s32 ringLo[2][kPack], curByte[2][kPack];
@@ -66,7 +66,7 @@ __device__ __forceinline__ u32 pack_entry(u32 sym, u32 nextState, u32 tableLog, 
 {
     const u32 nb = tableLog - highbit32(nextState);
     const u32 add = kind == 0 ? (u32)dLL_bits[sym] : kind == 1 ? sym : (u32)dML_bits[sym];
-    return (((nextState << nb) - tableSize) & 0xFFFFu) | (nb << 16) | (add << 20) | (sym << 25);
+    return (((nextState << nb) - tableSize) & 0xFFFFu) | (nb << 16) | ((nb + add) << 20) | (sym << 26);
 }
 
 // ZSTD_buildFSETable_body (U/ZstdDecompressBlock.cs:1571-1710) by the whole wave, as build_seq_dtable_wave (zmi_decode.h) but
@@ -190,8 +190,8 @@ __device__ __forceinline__ void seq_fields_batch(const SeqLds& L, u32 buf, u32 s
     if (have) {
         const u32 st = L.recSt[buf][sl][lane];
         const u32 qLL = T[kTabLL + (st & 1023u)], qML = T[kTabML + ((st >> 10) & 1023u)], qOF = T[kTabOF + (st >> 20)];
-        const u32 aLL = (qLL >> 20) & 31u, aML = (qML >> 20) & 31u, aOF = (qOF >> 20) & 31u;
-        const u32 bLL = dLL_base[qLL >> 25], bML = dML_base[qML >> 25], bOF = of_base(qOF >> 25);
+        const u32 aLL = ((qLL >> 20) & 63u) - ((qLL >> 16) & 15u), aML = ((qML >> 20) & 63u) - ((qML >> 16) & 15u), aOF = ((qOF >> 20) & 63u) - ((qOF >> 16) & 15u);
+        const u32 bLL = dLL_base[qLL >> 26], bML = dML_base[qML >> 26], bOF = of_base(qOF >> 26);
         s32 p = L.posBase[buf][sl] - (s32)L.recPos[buf][sl][lane];
         const u32 ofv = stream_field(sp, size, p, aOF); p -= (s32)aOF;
         const u32 mlv = stream_field(sp, size, p, aML); p -= (s32)aML;
@@ -316,7 +316,11 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
     // ---- the top 2 KiB of every stream into its ring (zeros outside the stream) ----
     s32 loA = 0, loB = 0;                                           // helper waves: lowest staged byte of their blocks (multiples of 4)
     auto stage = [&](u32 sl, const u8* sp, s32 size, s32 from, s32 to) {       // bytes [from, to), multiples of 4
-        for (s32 x = from + 4 * (s32)lane; x < to; x += 256) L.ring[sl][(u32)(x >> 2) & (kRingDw - 1)] = stream_dword_z(sp, size, x >> 2);
+        for (s32 x = from + 4 * (s32)lane; x < to; x += 256) {
+            const u32 ix = (u32)(x >> 2) & (kRingDw - 1), v = stream_dword_z(sp, size, x >> 2);
+            L.ring[sl][ix] = v;
+            if (ix < 3) L.ring[sl][kRingDw + ix] = v;
+        }
     };
     if (wave) {
         if (nbA) { const s32 hi = (sizeA + 3) & ~3; loA = hi - (s32)kRing; stage(slA, spA, sizeA, loA, hi); }
@@ -337,19 +341,20 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
                 const s32 ringLo = L.ringLo[buf][lane], pos0 = pos;
                 const u32* const R = L.ring[lane];
                 L.posBase[buf][lane] = pos0;
+                // The window: stream dwords dl .. dl + 3, at least bits [pos - 97, pos), out of the ring.  (Staged, always: a valid
+                // stream never reaches more than 16 bytes below its start, and the ring is staged down to 64 below.  A damaged stream
+                // that runs away further reads the lowest staged dwords instead — in bounds, wrong bits, states stay inside their
+                // tables by construction; the fields phase sees the negative positions and reports corruption, as it did when this
+                // case read zeros.)  A step's seven reads are issued at the END of the step before it, as soon as the states and the
+                // position they depend on exist: both LDS latencies of a step overlap instead of following each other.
+                s32 dl = ((pos - 1) >> 5) - 3;
+                const u32* Rw = R + ((u32)(4 * dl >= ringLo ? dl : (ringLo >> 2)) & (kRingDw - 1));
+                u32 w0 = Rw[0], w1 = Rw[1], w2 = Rw[2], w3 = Rw[3];
+                u32 eLL = mT[kTabLL + sLL], eML = mT[kTabML + sML], eOF = mT[kTabOF + sOF];
                 for (u32 k = 0; k < steps; ++k) {
-                    const u32 eLL = mT[kTabLL + sLL], eML = mT[kTabML + sML], eOF = mT[kTabOF + sOF];
-                    const s32 dl = ((pos - 1) >> 5) - 3;                // the window: stream dwords dl .. dl + 3, at least bits [pos - 97, pos)
-                    // the window comes out of the ring.  (Staged, always: a valid stream never reaches more than 16 bytes below its
-                    // start, and the ring is staged down to 64 below.  A damaged stream that runs away further reads the lowest staged
-                    // dwords instead — in bounds, wrong bits, states stay inside their tables by construction; the fields phase sees
-                    // the negative positions and reports corruption, as it did when this case read zeros.)
-                    const s32 dlc = 4 * dl >= ringLo ? dl : (ringLo >> 2);
-                    const u32 ix0 = (u32)dlc & (kRingDw - 1);
-                    const u32 w0 = R[ix0], w1 = R[(ix0 + 1) & (kRingDw - 1)], w2 = R[(ix0 + 2) & (kRingDw - 1)], w3 = R[(ix0 + 3) & (kRingDw - 1)];
                     L.recSt[buf][lane][k] = sLL | (sML << 10) | (sOF << 20); L.recPos[buf][lane][k] = (u16)(pos0 - pos);
                     const u32 nLL = (eLL >> 16) & 15u, nML = (eML >> 16) & 15u, nOF = (eOF >> 16) & 15u, nbTot = nLL + nML + nOF;
-                    const s32 q = pos - (s32)(((eLL >> 20) & 31u) + ((eML >> 20) & 31u) + ((eOF >> 20) & 31u)) - (s32)nbTot;
+                    const s32 q = pos - (s32)(((eLL >> 20) & 63u) + ((eML >> 20) & 63u) + ((eOF >> 20) & 63u));
                     const u32 rr = (u32)(q - 32 * dl), ix = rr >> 5;     // q >= pos - 89 >= 32 dl + 8
                     const u32 lo = ix == 0 ? w0 : ix == 1 ? w1 : ix == 2 ? w2 : w3;
                     const u32 hi = ix == 0 ? w1 : ix == 1 ? w2 : ix == 2 ? w3 : 0u;
@@ -358,6 +363,11 @@ __global__ __launch_bounds__(256) void seq_decode_kernel(const u8* __restrict__ 
                     sML = (eML & 0xFFFFu) + ((all >> nOF) & ~(0xFFFFFFFFu << nML));
                     sOF = (eOF & 0xFFFFu) + (all & ~(0xFFFFFFFFu << nOF));
                     pos = q;
+                    // the next step's reads (harmless after the last one: states and window stay in bounds)
+                    dl = ((pos - 1) >> 5) - 3;
+                    Rw = R + ((u32)(4 * dl >= ringLo ? dl : (ringLo >> 2)) & (kRingDw - 1));
+                    w0 = Rw[0]; w1 = Rw[1]; w2 = Rw[2]; w3 = Rw[3];
+                    eLL = mT[kTabLL + sLL]; eML = mT[kTabML + sML]; eOF = mT[kTabOF + sOF];
                 }
             }
             __builtin_amdgcn_s_setprio(0);
