@@ -1,6 +1,6 @@
-// tools/finder_lab.c - CPU model of the region parse with different candidate structures (rows per tile, true last-R occurrences,
-// round-granular hash chains), sized by the oracle's entropy stage.  Development aid, not part of the product or the tests.
-// build: gcc -O2 -Ioracle -o /tmp/lab tools/finder_lab.c oracle/libzso.so -Wl,-rpath,$PWD/oracle
+// tests/lab/finder_lab.c - CPU model of the region parse with different candidate structures (rows per tile, true last-R occurrences,
+// round-granular hash chains), sized by the oracle's entropy stage.  Experiment bench kept beside the tests (it links the oracle); not collected by pytest, not part of the product.
+// build: gcc -O2 -Ioracle -o /tmp/lab tests/lab/finder_lab.c oracle/libzso.so -Wl,-rpath,$PWD/oracle
 // run:   /tmp/lab file H B R MODE HLOG LAZY frame [GRAN [LAZYT]]   (MODE 0 per-tile rows, 1 last R occurrences, 2 chains)
 // finder lab: how much do window and candidate depth buy?  (CPU experiment, not part of the product)
 #include <stdio.h>

@@ -328,10 +328,10 @@ __device__ __forceinline__ void insert_tiles(LzLds& L, const u32 n, const u32 tF
 // link; then ds_max the group's own positions into the table.  LDS operations of one wave execute in program order, so a group
 // sees every group before it and nothing of itself: deterministic, no sort, 64 x 4 LDS instructions per tile.  (Exact links —
 // a stable radix sort of the tile by hash, neighbours in sorted order — were built first and measured: 7.3 us per tile against
-// 1.5 for this, for 0.2 - 1.4 % of compressed size on the CPU model of this parse, tools/finder_lab.c.)
+// 1.5 for this, for 0.2 - 1.4 % of compressed size on the CPU model of this parse, tests/lab/finder_lab.c.)
 // Links of the current tile and the three before it stay in LDS, all links go to global memory (2 bytes per position, L2), where
 // the walk follows them further back.
-// Measured with tools/finder_lab.c (same parse on the CPU): chains of depth 8 against one candidate per position: -7 % compressed
+// Measured with tests/lab/finder_lab.c (same parse on the CPU): chains of depth 8 against one candidate per position: -7 % compressed
 // size on text, -11 % on Python sources.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr u32 kHcCont  = 12;             // a position whose left neighbour holds a match this long takes its continuation unsearched
@@ -435,7 +435,7 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             // The four positions of a thread are searched one after the other: a position whose left neighbour found kHcCont
             // bytes or more takes that match's continuation (same offset, one byte shorter) without a search of its own — the
             // parse only ever looks at such a position for the lazy step, which a match that long does not lose
-            // (tools/finder_lab.c: 0.1 - 0.4 % of compressed size).  LDS gathers are what the search costs; this halves them.
+            // (tests/lab/finder_lab.c: 0.1 - 0.4 % of compressed size).  LDS gathers are what the search costs; this halves them.
 #pragma unroll
             for (u32 j = 0; j < 4; ++j) {
                 const u32 p = p0 + j;
