@@ -28,6 +28,7 @@
 //
 // LDS (one workgroup per CU, 158 KiB): chunk 64 KiB (+pad) | 64 KiB of hash tables | tile arrays.
 // HBM traffic per chunk: read n, write literals (<= n) + 8 B per sequence.
+#include <type_traits>
 #include "zmi_device.h"
 
 namespace zmi {
@@ -432,43 +433,58 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             // A candidate can only beat the best so far if it agrees with the position on the four bytes that END one past the
             // best length (the reference's own filter, U/ZstdLazy.cs:690-696): one unaligned dword per candidate instead of sixteen
             // bytes; only those that pass are measured in full.  pw = those four bytes of the position.
-            // The four positions of a thread are searched one after the other: a position whose left neighbour found kHcCont
-            // bytes or more takes that match's continuation (same offset, one byte shorter) without a search of its own — the
-            // parse only ever looks at such a position for the lazy step, which a match that long does not lose
-            // (tests/lab/finder_lab.c: 0.1 - 0.4 % of compressed size).  LDS gathers are what the search costs; this halves them.
-#pragma unroll
-            for (u32 j = 0; j < 4; ++j) {
+            // A position whose left neighbour found kHcCont bytes or more takes that match's continuation (same offset, one byte
+            // shorter) without a search of its own — the parse only ever looks at such a position for the lazy step, which a match
+            // that long does not lose (tests/lab/finder_lab.c: 0.1 - 0.4 % of compressed size).
+            // What the walk costs is instruction issue under divergence: in nearly every step SOME lane of the wave has a candidate
+            // to measure in full, so every step pays that path (measured: skipping 40 % of the positions, or two chains per lane in
+            // flight instead of one, both leave the time where it is; an attempt costs 1.0 - 1.7 ms per GiB).
+            // Positions 0 and 2 of a thread are walked side by side, then 1 and 3 (which may take their left neighbour's
+            // continuation): two chains in flight per lane hide each other's LDS latency.
+            auto link = [&](u32 cpos) -> u32 {
+                return cpos >= tileStart ? (u32)tilePred[cpos - tileStart]
+                     : cpos + kRing * kTilePos >= tileStart ? (u32)ring[((cpos >> kTileLog) % kRing) * kTilePos + (cpos & (kTilePos - 1))]
+                     : (u32)chainG[cpos];
+            };
+            auto measure = [&](auto J, u32 cpos, u32& pw) {           // the candidate passed the filter: its full length, up to 64
+                constexpr u32 j = decltype(J)::value;
                 const u32 p = p0 + j;
-                if (j > 0 && c[j] && best[j - 1] && bestLen[j - 1] >= kHcCont && bestLen[j - 1] < 64) {
-                    best[j] = best[j - 1] + 1; bestLen[j] = bestLen[j - 1] - 1; c[j] = 0;
-                }
-                u32 pw = (u32)a1[j];
-#pragma unroll 1
-                for (u32 d = 0; d < depth && c[j]; ++d) {
-                    const u32 cpos = c[j] - 1;
-                    const u32 chk = lds_load4(L.in, cpos + bestLen[j] - 3);
-                    const u32 nxt = cpos >= tileStart ? (u32)tilePred[cpos - tileStart]
-                                  : cpos + kRing * kTilePos >= tileStart ? (u32)ring[((cpos >> kTileLog) % kRing) * kTilePos + (cpos & (kTilePos - 1))]
-                                  : (u32)chainG[cpos];
-                    if (chk == pw) {
-                        u64 c1, c2;
-                        lds_load16(L.in, cpos, c1, c2);
-                        const u64 x1 = a1[j] ^ c1, x2 = a2[j] ^ c2;
-                        u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
-                        if (l == 16) {
-                            while (l < 64) {
-                                const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
-                                if (x) { l += ctz64(x) >> 3; break; }
-                                l += 8;
-                            }
-                            if (l > 64) l = 64;
-                        }
-                        if (l > n - p) l = n - p;
-                        if (l > bestLen[j]) { bestLen[j] = l; best[j] = c[j]; pw = lds_load4(L.in, p + l - 3); }
+                u64 c1, c2;
+                lds_load16(L.in, cpos, c1, c2);
+                const u64 x1 = a1[j] ^ c1, x2 = a2[j] ^ c2;
+                u32 l = x1 ? (ctz64(x1) >> 3) : 8u + (x2 ? (ctz64(x2) >> 3) : 8u);
+                if (l == 16) {
+                    while (l < 64) {
+                        const u64 x = lds_load8(L.in, p + l) ^ lds_load8(L.in, cpos + l);
+                        if (x) { l += ctz64(x) >> 3; break; }
+                        l += 8;
                     }
-                    c[j] = bestLen[j] >= 64 ? 0u : nxt;
+                    if (l > 64) l = 64;
                 }
-            }
+                if (l > n - p) l = n - p;
+                if (l > bestLen[j]) { bestLen[j] = l; best[j] = cpos + 1; pw = lds_load4(L.in, p + l - 3); }
+            };
+            auto pair_walk = [&](auto JA, auto JB) {
+                constexpr u32 ja = decltype(JA)::value, jb = decltype(JB)::value;
+                u32 pwa = (u32)a1[ja], pwb = (u32)a1[jb];
+#pragma unroll 1
+                for (u32 d = 0; d < depth && (c[ja] | c[jb]); ++d) {
+                    const bool ha = c[ja] != 0, hb = c[jb] != 0;
+                    const u32 ca = ha ? c[ja] - 1 : 0u, cb = hb ? c[jb] - 1 : 0u;      // (idle: position 0, in bounds, result unused)
+                    const u32 chka = lds_load4(L.in, ca + bestLen[ja] - 3), chkb = lds_load4(L.in, cb + bestLen[jb] - 3);
+                    const u32 nxa = link(ca), nxb = link(cb);
+                    if (ha) { if (chka == pwa) measure(JA, ca, pwa); c[ja] = bestLen[ja] >= 64 ? 0u : nxa; }
+                    if (hb) { if (chkb == pwb) measure(JB, cb, pwb); c[jb] = bestLen[jb] >= 64 ? 0u : nxb; }
+                }
+            };
+            auto take_over = [&](auto J) {                            // the left neighbour's match, one byte shorter
+                constexpr u32 j = decltype(J)::value;
+                if (c[j] && best[j - 1] && bestLen[j - 1] >= kHcCont && bestLen[j - 1] < 64) { best[j] = best[j - 1] + 1; bestLen[j] = bestLen[j - 1] - 1; c[j] = 0; }
+            };
+            using I0 = std::integral_constant<u32, 0>; using I1 = std::integral_constant<u32, 1>; using I2 = std::integral_constant<u32, 2>; using I3 = std::integral_constant<u32, 3>;
+            pair_walk(I0{}, I2{});
+            take_over(I1{}); take_over(I3{});
+            pair_walk(I1{}, I3{});
             u64 out4 = 0;
 #pragma unroll
             for (u32 j = 0; j < 4; ++j) out4 |= (u64)(best[j] & 0xFFFFu) << (16 * j);
