@@ -200,3 +200,17 @@ def test_level5_and_9_search_deeper_and_stay_near_the_oracle_at_the_same_frame_s
     print("level sizes", sizes, "oracle level 5, 256 KiB frames", ref, {k: round(v / ref, 4) for k, v in sizes.items()})
     assert sizes[5] <= 0.97 * sizes[3] and sizes[9] <= sizes[5] and sizes["5+sl5"] <= sizes[5]
     assert sizes[5] <= 1.09 * ref and sizes[9] <= 1.08 * ref, (sizes, ref)       # measured 1.069 / 1.058 (+ 2 %)
+
+
+def test_search_log_buys_ratio_monotonically(gpu_lib, oracle):
+    """ZSTD_c_searchLog at level 5: 1 << searchLog attempts down the hash chain (4 .. 32 used): every doubling may only shrink the
+    output (a longer match among more candidates), and all of them decode under the oracle."""
+    data = datagen.gen("text", 1 << 20, 9)
+    sizes = []
+    with z.Compressor(5) as c:
+        for sl in (2, 3, 4, 5):
+            c.SetParameter(104, sl)
+            comp = c.Wrap(data)
+            assert oracle.decompress(comp, len(data)) == data
+            sizes.append(len(comp))
+    assert sizes == sorted(sizes, reverse=True) and sizes[-1] < sizes[0], sizes
