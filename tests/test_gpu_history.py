@@ -214,3 +214,26 @@ def test_search_log_buys_ratio_monotonically(gpu_lib, oracle):
             assert oracle.decompress(comp, len(data)) == data
             sizes.append(len(comp))
     assert sizes == sorted(sizes, reverse=True) and sizes[-1] < sizes[0], sizes
+
+
+def test_levels_above_2_fall_back_to_level_1_where_a_match_finder_finds_nothing(gpu_lib, oracle):
+    """on Zipf bytes level >= 3 must not be both slower and larger than level 1.  A call of 4 MiB or more that leaves
+    strategy, window and history to the level samples 64 tiles of the input first (lz_probe_kernel); where next to nothing repeats,
+    level 1's finder and framing take the call: byte-identical to level 1.  Dense input, smaller calls and calls that set the
+    history themselves keep the level's own path."""
+    n = 4 << 20
+    for kind, falls_back in (("zipf", True), ("rand", True), ("text", False), ("mixed", False), ("runs", False)):
+        data = datagen.gen(kind, n, 17)
+        with z.Compressor(1) as c1, z.Compressor(5) as c5, z.Compressor(3) as c3:
+            a, b, c = c1.Wrap(data), c5.Wrap(data), c3.Wrap(data)
+            assert oracle.decompress(b, n) == data and oracle.decompress(c, n) == data
+            assert (a == b) == falls_back and (a == c) == falls_back, kind
+            if falls_back:
+                set_history(gpu_lib, c5, 32 << 10)              # asked for explicitly: multi-block frames whatever the data
+                forced = c5.Wrap(data)
+                assert forced != a and oracle.decompress(forced, n) == data
+                assert walk_frames(gpu_lib, forced)[0][0] == (256 << 10)
+        small = data[:(4 << 20) - 65536]                       # below the probe's floor: the level's own framing
+        with z.Compressor(5) as c5:
+            fr = walk_frames(gpu_lib, c5.Wrap(small))
+            assert len(fr[0][1]) == 8, "256 KiB frames of eight 32 KiB blocks"

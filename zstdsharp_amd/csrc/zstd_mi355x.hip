@@ -19,6 +19,7 @@ namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream);
+void launch_lz_probe(const u8* src, u64 srcSize, u32 nSamples, u32* out, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
@@ -275,9 +276,10 @@ static size_t cctx_sync_dictionary(ZSTD_CCtx* c)
 }
 
 // the compress pipeline over device-resident buffers
-static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+static size_t compress_device(ZSTD_CCtx* c, const CallParams& cpIn, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
 {
     hipStream_t s = c->stream;
+    CallParams cp = cpIn;
     if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
         u8 f[13]; size_t n = 0;
         f[n++] = 0x28; f[n++] = 0xB5; f[n++] = 0x2F; f[n++] = 0xFD;
@@ -299,6 +301,23 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
     const u32 plainReps[3] = { 1, 4, 8 };
     const u32* const initReps = fmtDict ? c->info.rep : plainReps;
     Resolved rs = resolve_call(cp, srcSize, chunkBytes);
+    // Input the match finder gets nothing out of (BASELINE's Zipf bytes, random or already compressed data): the history, smaller
+    // blocks and deeper search of the levels >= 3 only cost there — Zipf at level 5 came out 0.8 % LARGER than at level 1 (a frame
+    // header share and a Huffman table per 32 KiB instead of per 64 KiB) at an eighth of the speed.  So a call of 4 MiB or more that
+    // leaves strategy, window and history to the level first looks at 64 tiles of 4 KiB spread over the input (lz_probe_kernel:
+    // positions that repeat an earlier one of their tile; ~40 us with the read-back): fewer than 32 per tile on average (text has
+    // several hundred, Zipf bytes a handful) and the whole call takes level 1's finder and framing.  The decision is a function
+    // of the data alone (deterministic); a mixed input with a dense share keeps its level.
+    if (prefixLen == 0 && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0 && rs.cp.strategy > kStratFast && srcSize >= (4u << 20)) {
+        constexpr u32 kSamples = 64;
+        if (!cctx_workspace(c, 64)) return ZERR(kErrMemoryAllocation);
+        u32* const cnt = (u32*)c->total.p;
+        launch_lz_probe(d_src, srcSize, kSamples, cnt, s);
+        u32 repeats = 0;
+        if (hipMemcpyAsync(&repeats, cnt, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        if (repeats < kSamples * 32) { cp.level = 1; rs = resolve_call(cp, srcSize, chunkBytes); }
+    }
     // Cross-chunk history (the window the block loop carries, U/ZstdCompress.cs:4705-4807): blocks of 64 KiB - hist
     // bytes, each with the hist bytes in front of it as match-only history in LDS, frameBlocks of them to a frame (so a
     // match never reaches out of its frame and frames stay independent units for the decoder and for sharding).  Without a
