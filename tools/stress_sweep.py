@@ -23,6 +23,7 @@ def main():
         kind = rng.choice(kinds); level = rng.choice([1, 1, 3, 5, 5, 7, 9]); chk = rng.randrange(2); dk = rng.choice(list(dicts))
         n = rng.choice([rng.randrange(0, 300), rng.randrange(0, 70000), rng.randrange(0, 400000), 65536 * rng.randrange(1, 5) + rng.randrange(-2, 3),
                         32768 * rng.randrange(1, 40) + rng.randrange(-2, 3)])
+        if rng.randrange(200) == 0: n = rng.choice([4 << 20, (5 << 20) + 123, (4 << 20) + 65536 * 3 + 1])      # (calls large enough for the levels >= 3 sparse-input probe)
         data = datagen.gen(kind, n, rng.randrange(1 << 30))
         # cross-chunk history (row f-1): by level, off, or 16/32/48 KiB with frames of 128 KiB .. 1 MiB
         hist = rng.choice([(-1, 0), (-1, 0), (0, 0), (16 << 10, 128 << 10), (32 << 10, 256 << 10), (48 << 10, 1 << 20), (32 << 10, 64 << 10)])
