@@ -237,3 +237,19 @@ def test_levels_above_2_fall_back_to_level_1_where_a_match_finder_finds_nothing(
         with z.Compressor(5) as c5:
             fr = walk_frames(gpu_lib, c5.Wrap(small))
             assert len(fr[0][1]) == 8, "256 KiB frames of eight 32 KiB blocks"
+
+
+def test_a_long_stretch_without_matches_inside_a_call_is_compressed_as_level_1_would(gpu_lib, oracle):
+    """The sampling works per group of 16 frames; a stretch of 64 MiB or more without matches becomes a range of its own (level 1's
+    finder and framing), the rest keeps the level: the output is the concatenation of what the two parts give on their own.
+    Shorter stretches stay with their surroundings (a range is a pass, and a pass wants thousands of chunks)."""
+    sparse = datagen.gen("zipf", 72 << 20, 5)
+    dense = datagen.gen("text", 8 << 20, 6)
+    with z.Compressor(5) as c5, z.Compressor(1) as c1:
+        whole = c5.Wrap(sparse + dense)
+        assert whole == c1.Wrap(sparse) + c5.Wrap(dense)
+        assert oracle.decompress(whole, len(sparse) + len(dense)) == sparse + dense
+        short = datagen.gen("zipf", 8 << 20, 5) + dense                # 8 MiB of it: one range, the level's own path throughout
+        out = c5.Wrap(short)
+        assert out != c1.Wrap(short[:8 << 20]) + c5.Wrap(dense)
+        assert walk_frames(gpu_lib, out)[0][0] == (256 << 10) and len(walk_frames(gpu_lib, out)[0][1]) == 8

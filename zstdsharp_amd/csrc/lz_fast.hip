@@ -1557,44 +1557,46 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
 
 size_t lz_fast_lds_bytes() { return sizeof(LzLds); }
 
-// How much is there for a match finder to find?  nSamples tiles of 4 KiB spread evenly over the input; per tile, the positions
-// whose 6 bytes' hash was seen earlier in the same tile with the same tag and the same first four bytes (what the fast finder's
-// first-occurrence table would offer them) are counted into *out.  Text: several hundred per tile; Zipf or random bytes: a
-// handful.  (One workgroup per sample, reads 4 KiB: a few microseconds.)
-__global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ src, u64 srcSize, u32 nSamples, u32* __restrict__ out)
+// How much is there for a match finder to find?  The input in groups of groupBytes; per group, tilesPerGroup tiles of 4 KiB spread
+// evenly over it; per tile, the positions whose 6 bytes' hash was seen earlier in the same tile with the same tag and the same first
+// four bytes (what the fast finder's first-occurrence table would offer them) are counted into out[group].  Text: several hundred per
+// tile; Zipf or random bytes: a handful.  (One workgroup per tile, reads 4 KiB.)
+__global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ src, u64 srcSize, u64 groupBytes, u32 tilesPerGroup, u32* __restrict__ out)
 {
     __shared__ u32 firstSeen[1u << kHashLog];
     const u32 tid = threadIdx.x;
-    const u64 off = ((srcSize / nSamples) * blockIdx.x) & ~(u64)(kTilePos - 1);
+    const u32 g = blockIdx.x / tilesPerGroup, k = blockIdx.x % tilesPerGroup;
+    const u64 gStart = (u64)g * groupBytes, gLen = (srcSize - gStart) < groupBytes ? (srcSize - gStart) : groupBytes;
+    const u64 off = gStart + (((gLen / tilesPerGroup) * k) & ~(u64)(kTilePos - 1));
     const u8* __restrict__ in = src + off;
     const u32 avail = (u32)((srcSize - off) < kTilePos + 8 ? (srcSize - off) : kTilePos + 8);      // bytes readable from `in`
     for (u32 i = tid; i < (1u << kHashLog); i += 256) firstSeen[i] = 0xFFFFFFFFu;
     __syncthreads();
     u32 h[16];
 #pragma unroll
-    for (u32 k = 0; k < 16; ++k) {
-        const u32 q = k * 256 + tid;
-        h[k] = 0;
-        if (q + 8 <= avail) { h[k] = hash6p(readLE64(in + q)); atomicMin(&firstSeen[hidx(h[k])], (q << 16) | htag(h[k])); }
+    for (u32 j = 0; j < 16; ++j) {
+        const u32 q = j * 256 + tid;
+        h[j] = 0;
+        if (q + 8 <= avail) { h[j] = hash6p(readLE64(in + q)); atomicMin(&firstSeen[hidx(h[j])], (q << 16) | htag(h[j])); }
     }
     __syncthreads();
     u32 cnt = 0;
 #pragma unroll
-    for (u32 k = 0; k < 16; ++k) {
-        const u32 q = k * 256 + tid;
+    for (u32 j = 0; j < 16; ++j) {
+        const u32 q = j * 256 + tid;
         if (q + 8 <= avail) {
-            const u32 f = firstSeen[hidx(h[k])], fq = f >> 16;
-            if (fq < q && (f & 0xFFFFu) == htag(h[k]) && readLE32(in + fq) == readLE32(in + q)) ++cnt;
+            const u32 f = firstSeen[hidx(h[j])], fq = f >> 16;
+            if (fq < q && (f & 0xFFFFu) == htag(h[j]) && readLE32(in + fq) == readLE32(in + q)) ++cnt;
         }
     }
     cnt = wave_sum(cnt);
-    if (lane_id() == 0 && cnt) atomicAdd(out, cnt);
+    if (lane_id() == 0 && cnt) atomicAdd(&out[g], cnt);
 }
 
-void launch_lz_probe(const u8* src, u64 srcSize, u32 nSamples, u32* out, hipStream_t stream)
+void launch_lz_probe(const u8* src, u64 srcSize, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream)
 {
-    (void)hipMemsetAsync(out, 0, sizeof(u32), stream);
-    hipLaunchKernelGGL(lz_probe_kernel, dim3(nSamples), dim3(256), 0, stream, src, srcSize, nSamples, out);
+    (void)hipMemsetAsync(out, 0, (size_t)nGroups * sizeof(u32), stream);
+    hipLaunchKernelGGL(lz_probe_kernel, dim3(nGroups * tilesPerGroup), dim3(256), 0, stream, src, srcSize, groupBytes, tilesPerGroup, out);
 }
 
 #ifdef ZMI_LZ_STAMPS

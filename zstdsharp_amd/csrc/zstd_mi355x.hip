@@ -19,7 +19,7 @@ namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream);
-void launch_lz_probe(const u8* src, u64 srcSize, u32 nSamples, u32* out, hipStream_t stream);
+void launch_lz_probe(const u8* src, u64 srcSize, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
@@ -120,7 +120,7 @@ struct ZSTD_CCtx_s {
     int windowLog = 0, hashLog = 0, chainLog = 0, searchLog = 0, minMatch = 0, targetLength = 0, strategy = 0;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf seqs, lits, meta, tables, slots, offsets, total, cand, stageSrc, stageDst;
+    DevBuf seqs, lits, meta, tables, slots, offsets, total, cand, probe, stageSrc, stageDst;
     u32 lastChunks = 0;         // chunks of the last pass (debug hook)
     const u8* lastSrc = nullptr; u32 lastChunkBytes = 0;     // its source (debug hook: chunks without sequences keep their literals there)
     u32 passChunks = 16384;     // chunks per pass: 1 GiB of input bounds the HBM workspace to ~4.2 GiB
@@ -275,11 +275,10 @@ static size_t cctx_sync_dictionary(ZSTD_CCtx* c)
     return 0;
 }
 
-// the compress pipeline over device-resident buffers
-static size_t compress_device(ZSTD_CCtx* c, const CallParams& cpIn, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+// the compress pipeline over device-resident buffers: one range of the input with one set of parameters (see compress_device)
+static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize, bool& first)
 {
     hipStream_t s = c->stream;
-    CallParams cp = cpIn;
     if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
         u8 f[13]; size_t n = 0;
         f[n++] = 0x28; f[n++] = 0xB5; f[n++] = 0x2F; f[n++] = 0xFD;
@@ -301,23 +300,6 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cpIn, u8* d_dst, s
     const u32 plainReps[3] = { 1, 4, 8 };
     const u32* const initReps = fmtDict ? c->info.rep : plainReps;
     Resolved rs = resolve_call(cp, srcSize, chunkBytes);
-    // Input the match finder gets nothing out of (BASELINE's Zipf bytes, random or already compressed data): the history, smaller
-    // blocks and deeper search of the levels >= 3 only cost there — Zipf at level 5 came out 0.8 % LARGER than at level 1 (a frame
-    // header share and a Huffman table per 32 KiB instead of per 64 KiB) at an eighth of the speed.  So a call of 4 MiB or more that
-    // leaves strategy, window and history to the level first looks at 64 tiles of 4 KiB spread over the input (lz_probe_kernel:
-    // positions that repeat an earlier one of their tile; ~40 us with the read-back): fewer than 32 per tile on average (text has
-    // several hundred, Zipf bytes a handful) and the whole call takes level 1's finder and framing.  The decision is a function
-    // of the data alone (deterministic); a mixed input with a dense share keeps its level.
-    if (prefixLen == 0 && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0 && rs.cp.strategy > kStratFast && srcSize >= (4u << 20)) {
-        constexpr u32 kSamples = 64;
-        if (!cctx_workspace(c, 64)) return ZERR(kErrMemoryAllocation);
-        u32* const cnt = (u32*)c->total.p;
-        launch_lz_probe(d_src, srcSize, kSamples, cnt, s);
-        u32 repeats = 0;
-        if (hipMemcpyAsync(&repeats, cnt, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
-        if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-        if (repeats < kSamples * 32) { cp.level = 1; rs = resolve_call(cp, srcSize, chunkBytes); }
-    }
     // Cross-chunk history (the window the block loop carries, U/ZstdCompress.cs:4705-4807): blocks of 64 KiB - hist
     // bytes, each with the hist bytes in front of it as match-only history in LDS, frameBlocks of them to a frame (so a
     // match never reaches out of its frame and frames stay independent units for the decoder and for sharding).  Without a
@@ -355,7 +337,6 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cpIn, u8* d_dst, s
     if (regionParse && !cctx_cand_workspace(c, passChunks, hcChains)) return ZERR(kErrMemoryAllocation);
     const u32 strategy = rs.cp.strategy < kStratGreedy ? rs.cp.strategy : (u32)kStratGreedy;      // ZSTD_selectEncodingType's < lazy heuristic is the one seq_encode holds (U/ZstdCompressSequences.cs:400-469): levels whose strategy is lazy or above get greedy's constants
     size_t produced = 0;
-    bool first = true;
     for (u64 c0 = 0; c0 < totalChunks; c0 += passChunks) {
         const u32 nChunks = (u32)((totalChunks - c0) < passChunks ? (totalChunks - c0) : passChunks);
         const u8* src = d_src + c0 * chunkBytes;
@@ -387,6 +368,76 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cpIn, u8* d_dst, s
     return produced;
 }
 
+// Level >= 3 framing of a call that leaves strategy, window and history to the level: (block bytes, blocks per frame)
+static void level_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t srcSize, u32& chunkBytes, u32& frameBlocks)
+{
+    const Resolved r0 = resolve_call(cp, srcSize, kChunkSize);
+    chunkBytes = kChunkSize; frameBlocks = 0;
+    const int hb = (r0.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (r0.cp.strategy == kStratDfast ? (16 << 10) : (32 << 10)) : 0;
+    if (hb <= 0 || srcSize <= kChunkSize) return;
+    const Resolved rf = resolve_call(cp, srcSize < c->frameBytes ? srcSize : c->frameBytes, c->frameBytes);
+    if (rf.finder != 0) chunkBytes = kChunkSize - round_tile((size_t)hb);
+    frameBlocks = c->frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
+}
+
+// Input the match finder gets nothing out of (BASELINE's Zipf bytes, random or already compressed data): the history, smaller blocks
+// and deeper search of the levels >= 3 only cost there — Zipf at level 5 came out 0.8 % LARGER than at level 1 (a frame header share
+// and a Huffman table per 32 KiB instead of per 64 KiB) at an eighth of the speed, and in a mixed input such stretches took a third
+// of the match finder's time.  So a call of 4 MiB or more that leaves strategy, window and history to the level is first looked at
+// in groups of 16 frames (~4 MiB): lz_probe_kernel counts, in eight 4 KiB tiles per group, the positions that repeat an earlier one of
+// their tile (text: several hundred per tile; Zipf bytes: a handful; ~40 us per GiB with the read-back).  Runs of groups below 32
+// per tile — the whole call, or at least 64 MiB of it — are compressed as level 1 would (its finder, independent 64 KiB frames: the
+// same bytes level 1 writes for them), the rest by the level's own path; a group boundary is a frame boundary of both.  The decision
+// is a function of the data alone.
+static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+{
+    bool first = true;
+    bool probe = srcSize >= (4u << 20) && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0;
+    if (probe) {
+        if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
+        if (cp.useDict && dict_prefix_len(c, srcSize)) probe = false;
+        else if (resolve_call(cp, srcSize, kChunkSize).cp.strategy <= kStratFast) probe = false;
+    }
+    if (!probe) return compress_range(c, cp, d_dst, dstCapacity, d_src, srcSize, first);
+    u32 chunkBytes, frameBlocks;
+    level_framing(c, cp, srcSize, chunkBytes, frameBlocks);
+    const size_t group = (size_t)16 * (frameBlocks ? (size_t)frameBlocks * chunkBytes : (size_t)kChunkSize * 4);      // a multiple of 64 KiB
+    const u32 nGroups = (u32)((srcSize + group - 1) / group);
+    constexpr u32 kTilesPerGroup = 8;
+    if (!c->probe.ensure((size_t)nGroups * sizeof(u32))) return ZERR(kErrMemoryAllocation);
+    launch_lz_probe(d_src, srcSize, group, nGroups, kTilesPerGroup, (u32*)c->probe.p, c->stream);
+    std::vector<u32> counts;
+    try { counts.resize(nGroups); } catch (...) { return ZERR(kErrMemoryAllocation); }
+    if (hipMemcpyAsync(counts.data(), c->probe.p, (size_t)nGroups * sizeof(u32), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZERR(kErrGeneric);
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    CallParams cpSparse = cp; cpSparse.level = 1;
+    // a range is a pass of its own, and a pass needs thousands of chunks to fill the chip (the entropy stage walks serial chains per
+    // chunk): a stretch without matches counts only if it is the whole call or at least 64 MiB long — measured on the mixed bench
+    // input, whose 6.4 MiB pieces as ranges of their own took 1.7 x the time of one pass over everything
+    std::vector<u8> sp;
+    try { sp.resize(nGroups); } catch (...) { return ZERR(kErrMemoryAllocation); }
+    for (u32 g = 0; g < nGroups; ++g) sp[g] = counts[g] < kTilesPerGroup * 32;
+    const u32 minRun = (u32)(((size_t)64 << 20) / group);
+    for (u32 g = 0; g < nGroups; ) {
+        u32 e = g + 1;
+        while (e < nGroups && sp[e] == sp[g]) ++e;
+        if (sp[g] && e - g < minRun && !(g == 0 && e == nGroups)) for (u32 k = g; k < e; ++k) sp[k] = 0;
+        g = e;
+    }
+    size_t produced = 0;
+    for (u32 g = 0; g < nGroups; ) {
+        const bool sparse = sp[g] != 0;
+        u32 e = g + 1;
+        while (e < nGroups && (sp[e] != 0) == sparse) ++e;
+        const size_t off = (size_t)g * group, len = (e == nGroups ? srcSize : (size_t)e * group) - off;
+        const size_t r = compress_range(c, sparse ? cpSparse : cp, d_dst + produced, dstCapacity > produced ? dstCapacity - produced : 0, d_src + off, len, first);
+        if (isErr(r)) return r;
+        produced += r;
+        g = e;
+    }
+    return produced;
+}
+
 // ======================================================================================================
 extern "C" {
 
@@ -398,7 +449,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
     if (c->deviceOk) {
         (void)hipSetDevice(c->device);
         if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
-        c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release(); c->cand.release();
+        c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release(); c->cand.release(); c->probe.release();
         c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release(); c->dictFullDev.release(); c->dictInfoDev.release();
         c->timer.destroy();
         if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
