@@ -162,6 +162,10 @@ size_t ZSTDMI_debugGetChunk(ZSTD_CCtx* cctx, size_t chunkIdx, ZSTDMI_Seq* seqs, 
  * (0 = "store raw", the reference's ZSTD_entropyCompressSeqStore convention) */
 size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* cctx, void* dst, size_t dstCapacity, const ZSTDMI_Seq* seqs, size_t nbSeq,
                                 const void* lits, size_t litSize, size_t srcSize);
+/* the entropy stage of ONE chunk whose ChunkMeta is taken as given, WITHOUT the host's range checks, over a seqStore filled with the
+ * byte `fill`: what a faulty match finder would hand over.  The kernels must bound every size themselves (meta_checked, the
+ * bitstream room): returns the bytes the chunk's frame would take, never faults.  tests/test_gpu_boundary.py */
+size_t ZSTDMI_debugPoisonedChunk(ZSTD_CCtx* cctx, unsigned nbSeq, unsigned litSize, unsigned srcSize, unsigned fill);
 
 #ifdef __cplusplus
 }

@@ -98,6 +98,15 @@ def test_parameters_without_a_device():
                 c.SetParameter(param, v)
             assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_outOfBound, (param, v)
         c.SetParameter(param, 0)
+    # frame parameters: ZSTD_c_windowLog 10 .. 31 (below 16: frames of 1 << windowLog bytes), ZSTD_c_contentSizeFlag 0 / 1
+    for v in (10, 11, 15, 16, 17, 27, 31, 0):
+        c.SetParameter(101, v); assert c.GetParameter(101) == v
+    for v in (9, 32, -1):
+        with pytest.raises(ZstdException) as e:
+            c.SetParameter(101, v)
+        assert e.value.Code == ZSTD_ErrorCode.ZSTD_error_parameter_outOfBound
+    c.SetParameter(200, 0); assert c.GetParameter(200) == 0
+    c.SetParameter(200, 1); assert c.GetParameter(200) == 1
     c.SetParameter(107, 2)
     c.SetParameter(105, 5)                                 # doubleFast's short hash is 5 bytes wide
     c.SetParameter(105, 0); c.SetParameter(107, 0)

@@ -124,3 +124,135 @@ def test_streaming_refuses_oversized_windows_before_allocating(gpu_lib):
         d.SetParameter(ZSTD_d_windowLogMax, 16)
         assert DecompressionStream(io.BytesIO(comp), decompressor=d).ReadToEnd() == data
         assert d.Unwrap(comp) == data            # the one-shot path has no window limit (U/ZstdDecompress.cs:1062-1214)
+
+
+def _frames(blob, oracle):
+    """[(window the header declares, content size or None, compressed bytes)] of every frame, from the headers alone"""
+    out, pos = [], 0
+    while pos < len(blob):
+        fhd = blob[pos + 4]
+        single, fcs_id, did = (fhd >> 5) & 1, fhd >> 6, (0, 1, 2, 4)[fhd & 3]
+        p = pos + 5
+        window = None
+        if not single:
+            wl = blob[p]; p += 1
+            window = 1 << ((wl >> 3) + 10); window += (window >> 3) * (wl & 7)
+        p += did
+        fcs = None
+        if fcs_id == 0 and single: fcs = blob[p]
+        elif fcs_id == 1: fcs = int.from_bytes(blob[p:p + 2], "little") + 256
+        elif fcs_id == 2: fcs = int.from_bytes(blob[p:p + 4], "little")
+        elif fcs_id == 3: fcs = int.from_bytes(blob[p:p + 8], "little")
+        fs = oracle.lib().zso_findFrameCompressedSize(blob[pos:pos + (2 << 20)], min(len(blob) - pos, 2 << 20))
+        assert not oracle.is_error(fs)
+        out.append((fcs if single else window, fcs, fs))
+        pos += fs
+    return out
+
+
+@pytest.mark.parametrize("level", [1, 3, 5])
+@pytest.mark.parametrize("windowLog", [10, 11, 12, 15, 16, 17])
+def test_window_log_is_honoured_by_every_frame(gpu_lib, oracle, level, windowLog):
+    """ZSTD_c_windowLog (U/ZstdCompress.cs:4690-4712, 4817-4929; the window's low limit U/ZstdCompressInternal.cs:787-813): the
+    reference never lets an offset or a block exceed 1 << windowLog.  Here: below 16, frames of 1 << windowLog bytes (a frame is its
+    own window); 16, independent 64 KiB frames at every level; above, multi-block frames of at most 1 << windowLog of content.  A
+    decoder limited to that windowLog (ZSTD_d_windowLogMax) accepts every frame, as T/ZstdNetSteamingTests.cs:290-309 requires."""
+    data = datagen.gen("text", 300000, 5) + datagen.gen("zipf", 70001, 6)
+    with z.Compressor(level) as c:
+        c.SetParameter(101, windowLog)
+        assert c.GetParameter(101) == windowLog
+        c.SetParameter(201, 1)
+        comp = c.Wrap(data)
+    fr = _frames(comp, oracle)
+    assert max(w for w, _, _ in fr) <= 1 << windowLog, (max(w for w, _, _ in fr), windowLog)
+    assert sum(n for _, n, _ in fr) == len(data)
+    assert oracle.decompress(comp, len(data)) == data
+    with z.Decompressor() as d:
+        assert d.Unwrap(comp) == data
+    with DecompressionStream(io.BytesIO(comp), 4096) as ds:
+        ds.SetParameter(ZSTD_d_windowLogMax, max(windowLog, 10))
+        assert ds.ReadToEnd(1 << 16) == data
+    if windowLog > 16 and level == 1:
+        with z.Compressor(level) as c:
+            c.SetParameter(201, 1)
+            plain = c.Wrap(data)
+        assert len(comp) < len(plain), "a window above 64 KiB must buy something on text at level 1"
+
+
+@pytest.mark.parametrize("level,n", [(1, 0), (1, 1), (1, 1000), (1, 65536), (1, 200001), (3, 700000), (5, 700000)])
+def test_content_size_flag_off_writes_window_descriptor_frames(gpu_lib, oracle, level, n):
+    """ZSTD_c_contentSizeFlag = 0 (ZSTD_writeFrameHeader, U/ZstdCompress.cs:4817-4929): no content size in any header, a window
+    descriptor instead; the window holds the whole frame (no offset, no block beyond it).  ZSTD_decompressBound is then an upper
+    bound (blocks x block size), which is what Unwrap sizes its destination with."""
+    data = datagen.gen("text", n, 8)
+    with z.Compressor(level) as c:
+        c.SetParameter(200, 0)                    # ZSTD_c_contentSizeFlag
+        assert c.GetParameter(200) == 0
+        comp = c.Wrap(data)
+        c.SetParameter(201, 1)
+        comp_chk = c.Wrap(data)
+    for blob in (comp, comp_chk):
+        fr = _frames(blob, oracle)
+        assert all(fcs is None for _, fcs, _ in fr), "no frame may carry a content size"
+        bound = gpu_lib.ZSTD_decompressBound(blob, len(blob))
+        assert n <= bound <= n + len(fr) * 131072
+        assert oracle.decompress(blob, max(bound, 1)) == data
+        with z.Decompressor() as d:
+            assert d.Unwrap(blob) == data
+    assert len(comp_chk) == len(comp) + 4 * len(_frames(comp, oracle))
+    # frame sizes: every declared window covers the frame's regenerated size
+    pos = 0
+    for (w, _, fs) in _frames(comp, oracle):
+        piece = oracle.decompress(comp[pos:pos + fs], 1 << 20)
+        assert len(piece) <= w, (len(piece), w)
+        pos += fs
+
+
+def test_entropy_stage_bounds_a_poisoned_chunk_record(gpu_lib, oracle):
+    """The entropy kernels take sizes from the ChunkMeta the match finder left (nbSeq, litSize, srcSize).  A faulty finder — or an
+    experiment build without its emit phase, gpurun_out/call32.log — must not become an out-of-bounds access: every consumer bounds
+    the record (meta_checked) and seq_encode bounds its bitstream.  Garbage in, a bounded frame size out, and the context still works."""
+    data = datagen.gen("text", 100000, 2)
+    with z.Compressor(1) as c:
+        for nbSeq, litSize, srcSize, fill in ((16384, 65536, 65536, 0xFF), (0xFFFFFFFF, 5, 65536, 0x00), (100, 0xFFFFFFFF, 65536, 0xA5),
+                                              (16384, 0, 65536, 0xFF), (7, 7, 0xFFFFFFFF, 0x5A), (20000, 70000, 65536, 0x11), (16384, 65536, 65536, 0x80)):
+            r = gpu_lib.ZSTDMI_debugPoisonedChunk(c.cctx, nbSeq, litSize, srcSize, fill)
+            assert not is_error(r), (nbSeq, litSize, srcSize, fill, get_error_code(r))
+            assert r <= 65536 + 512, r
+        comp = c.Wrap(data)
+    assert oracle.decompress(comp, len(data)) == data
+
+
+def test_target_length_keeps_huffman_literals_on_sparse_input(gpu_lib, oracle):
+    """Level 5 + ZSTD_c_targetLength on input without matches: the sparse-input probe must not hand the call to level 1's settings
+    WITH the caller's targetLength (at the fast strategy that means raw literals, U/ZstdCompressInternal.cs:146-173): the size stays
+    at what Huffman literals give."""
+    data = datagen.gen("zipf", 6 << 20, 4)
+    with z.Compressor(1) as c:
+        l1 = c.Wrap(data)
+    with z.Compressor(5) as c:
+        c.SetParameter(ZSTD_c_targetLength, 16)
+        l5 = c.Wrap(data)
+    assert oracle.decompress(l5, len(data)) == data
+    assert len(l5) <= len(l1) * 1.02, (len(l5), len(l1))
+
+
+def test_redundancy_at_a_distance_keeps_the_levels_history(gpu_lib, oracle):
+    """The sparse-input probe (levels >= 3 fall back to level 1's path where the finder finds nothing) must also see redundancy
+    that only shows at 4 - 64 KiB: a random 16 KiB record repeated repeats nothing inside one 4 KiB tile, yet the level's history
+    finds every repeat.  Level 5 by itself must write what it writes with the history forced on, not level 1's frames."""
+    import numpy as np
+    rng = np.random.default_rng(12)
+    recs = [rng.integers(0, 256, 16384, dtype=np.uint8).tobytes() for _ in range(24)]
+    order = rng.integers(0, 24, 6 * 64)                      # 6 MiB: every record comes back about 16 times
+    data = b"".join(recs[i] + recs[i] for i in order)[:6 << 20]   # (each record twice in a row: a repeat 16 KiB back)
+    with z.Compressor(5) as c:
+        auto = c.Wrap(data)
+        assert gpu_lib.ZSTDMI_CCtx_setHistory(c.cctx, 32 << 10, 0) == 0
+        forced = c.Wrap(data)
+    with z.Compressor(1) as c:
+        l1 = c.Wrap(data)
+    assert oracle.decompress(auto, len(data)) == data
+    print(f"distance-only redundancy: level 5 {len(auto) / len(data):.4f}, history forced {len(forced) / len(data):.4f}, level 1 {len(l1) / len(data):.4f}")
+    assert auto == forced, "the level's own path (history in multi-block frames), not the sparse-input fallback"
+    assert auto != l1 and len(auto) <= len(l1) * 1.001, (len(auto), len(l1))

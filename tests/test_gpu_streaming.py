@@ -115,24 +115,60 @@ def test_round_trip_batch_to_streaming_and_back(gpu_lib, oracle):
     assert oracle.decompress(tmp.getvalue(), len(data)) == data
 
 
+def frame_windows(blob):
+    """(window, content size or None) of every frame of a stream, from the headers alone (U/ZstdDecompress.cs:462-634)."""
+    import oracle_lib as o
+    out, pos = [], 0
+    while pos < len(blob):
+        fhd = blob[pos + 4]
+        single, fcs_id, did = (fhd >> 5) & 1, fhd >> 6, (0, 1, 2, 4)[fhd & 3]
+        p = pos + 5
+        window = None
+        if not single:
+            wl = blob[p]; p += 1
+            window = (1 << ((wl >> 3) + 10)); window += (window >> 3) * (wl & 7)
+        p += did
+        fcs = None
+        if fcs_id == 0 and single: fcs = blob[p]
+        elif fcs_id == 1: fcs = int.from_bytes(blob[p:p + 2], "little") + 256
+        elif fcs_id == 2: fcs = int.from_bytes(blob[p:p + 4], "little")
+        elif fcs_id == 3: fcs = int.from_bytes(blob[p:p + 8], "little")
+        out.append((fcs if single else window, fcs))
+        pos += o.lib().zso_findFrameCompressedSize(blob[pos:pos + (1 << 20)], min(len(blob) - pos, 1 << 20))
+    return out
+
+
+@pytest.mark.parametrize("useDict", [False, True])
 @pytest.mark.parametrize("advanced", [False, True])
 @pytest.mark.parametrize("zstdBufferSize", [1, 7, 1024, 65535, LARGE + 1])
 @pytest.mark.parametrize("copyBufferSize", [101, 65535, LARGE + 1])
-def test_round_trip_streaming_to_streaming(gpu_lib, oracle, advanced, zstdBufferSize, copyBufferSize):
-    """T/ZstdNetSteamingTests.cs:269-318 without the dictionary axis (dictionaries are out of scope) and without the
-    smallest copy sizes on the full 1 MiB (python loop time); the small ones run on 50 000 bytes below."""
+def test_round_trip_streaming_to_streaming(gpu_lib, oracle, useDict, advanced, zstdBufferSize, copyBufferSize):
+    """T/ZstdNetSteamingTests.cs:269-318, every axis: dictionary (a formatted one; the reference trains its own with ZDICT, which
+    is outside the path), advanced = ZSTD_c_windowLog 11 + checksum on the compression stream and ZSTD_d_windowLogMax 11 on the
+    decompression stream — so no frame may declare a window above 2 KiB.  (Without the smallest copy sizes on the full 1 MiB:
+    python loop time; the small ones run on 50 000 bytes below.)"""
     data = sequential(LARGE)
+    dic = oracle.make_dictionary(datagen.gen("text", 20000, 3) + sequential(4096), datagen.gen("text", 60000, 4), 4242) if useDict else None
     tmp = io.BytesIO()
     with CompressionStream(tmp, 3, zstdBufferSize) as cs:
+        cs.LoadDictionary(dic)
         if advanced:
+            cs.SetParameter(101, 11)                    # ZSTD_c_windowLog
             cs.SetParameter(201, 1)                     # ZSTD_c_checksumFlag
         for lo in range(0, len(data), copyBufferSize):
             cs.Write(data, lo, min(copyBufferSize, len(data) - lo))
     blob = tmp.getvalue()
-    assert oracle.decompress(blob, len(data)) == data
+    if advanced:
+        fw = frame_windows(blob)
+        assert max(w for w, _ in fw) <= 2048 and sum(c for _, c in fw) == len(data)
+    if not useDict:
+        assert oracle.decompress(blob, len(data)) == data
     tmp.seek(0)
     out = bytearray()
     with DecompressionStream(tmp, zstdBufferSize if zstdBufferSize >= 7 else 7) as ds:
+        ds.LoadDictionary(dic)
+        if advanced:
+            ds.SetParameter(100, 11)                    # ZSTD_d_windowLogMax
         while True:
             b = ds.Read(copyBufferSize)
             if not b:

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 3 --warmup 1 --no-cpu-baseline ${BENCH_ARGS}"
+ARGS="--steps 3 --warmup 1 --no-cpu-baseline --no-extra ${BENCH_ARGS}"
 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -o stats -- python3 "$ROOT/bench.py" $ARGS > "$OUT/${TAG}_bench_under_stats.json" 2> "$OUT/stats.err"
 echo "stats pass done"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d "$OUT/fetch" -o fetch -- python3 "$ROOT/bench.py" $ARGS > "$OUT/fetch.out" 2> "$OUT/fetch.err"

@@ -67,6 +67,7 @@ SIGNATURES = {
     "ZSTDMI_DCtx_getStageTimes": (c_int, [c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.POINTER(ctypes.c_char_p), c_int]),
     "ZSTDMI_debugGetChunk": (c_size_t, [c_void_p, c_size_t, ctypes.POINTER(ZSTDMI_Seq), c_size_t, ctypes.POINTER(c_size_t),
                                         c_void_p, c_size_t, ctypes.POINTER(c_size_t)]),
+    "ZSTDMI_debugPoisonedChunk": (c_size_t, [c_void_p, c_uint, c_uint, c_uint, c_uint]),
     "ZSTDMI_debugEntropyBlock": (c_size_t, [c_void_p, c_void_p, c_size_t, ctypes.POINTER(ZSTDMI_Seq), c_size_t,
                                             c_void_p, c_size_t, c_size_t]),
 }

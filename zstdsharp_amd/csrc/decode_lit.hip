@@ -236,10 +236,6 @@ typedef __attribute__((address_space(3))) const u16 lds_u16_t;
 #define ZMI_LDS_U16(off) (*(lds_u16_t*)(size_t)(off))
 __device__ __forceinline__ u32 lds_offset(const void* p) { return (u32)(size_t)(__attribute__((address_space(3))) const u8*)p; }
 
-#ifndef ZMI_LIT_EXPERIMENT
-#define ZMI_LIT_EXPERIMENT 0            /* timing-only diagnostic builds (tools/lit_experiments.py): 1 no table lookup, 2 no stream loads, 3 no stores */
-#endif
-
 // quadStore (uniform over the 4 lanes of a quad that decode the 4 streams of one block): the first nQuad symbols (a multiple of
 // 64, the same for the 4 lanes) are written through a 4 x 4 transpose inside the quad (v_mov_dpp quad_perm, no LDS): lane j
 // then stores bytes [16 j, 16 j + 16) of stream p's 64-byte piece, p = 0 .. 3, so that every store instruction writes 64
@@ -257,11 +253,7 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u32 tOff, const u32 n
     // (nPair2 = twice the number of pair entries: t, which carries the bit behind the index, is below it exactly for them)
     auto sym1 = [&](u32& w, u32& r, u32& q, u32& spare) -> u32 {
         const u32 t = w >> (31 - IDX);
-#if ZMI_LIT_EXPERIMENT == 1
-        const u32 e = 26u | ((t & 0xFFu) << 8);
-#else
         const u32 e = ZMI_LDS_U16(tOff | (t & kMask));
-#endif
         u32 e2 = e, sh = 8;
         if (PAIRS) { const bool isPair = t < nPair2; e2 = isPair ? 31u - IDX : e; sh = isPair ? (t & 1u) << 3 : 8u; }
         w = __builtin_amdgcn_alignbit(w, r, e2);
@@ -283,12 +275,8 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u32 tOff, const u32 n
         u64 lowHi = 0, lowLo = 0;
         auto load_low = [&]() {
             const s32 lp = ptr - 16;
-#if ZMI_LIT_EXPERIMENT == 2
-            lowHi = lowHi * 0x9E3779B97F4A7C15ull + (u64)lp; lowLo = lowHi ^ cont;
-#else
             const u8* a = src + (lp > 0 ? lp : 0);
             lowLo = readLE64(a); lowHi = readLE64(a + 8);
-#endif
         };
         auto fix_low = [&]() {           // bytes below the stream's start are zero (only the last steps of a stream get here)
             const s32 lp = ptr - 16;
@@ -354,15 +342,11 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u32 tOff, const u32 n
                         const u32 nb2 = (u32)__builtin_amdgcn_mov_dpp((int)b[4 * (p ^ 2u) + k], 0x4E, 0xF, 0xF, true);    // lane ^ 2's piece p ^ 2
                         c[4 * p + k] = (odd2 == (bool)(p & 2u)) ? b[4 * p + k] : nb2;
                     }
-#if ZMI_LIT_EXPERIMENT == 3
-                if ((i & 1023u) == 0) { u32 x = 0; for (u32 g = 0; g < 16; ++g) x ^= c[g]; *(u32u*)(out + i) = x; }
-#else
 #pragma unroll
                 for (u32 p = 0; p < 4; ++p) {
                     u32u* o = (u32u*)(tbase + (size_t)p * seg + i);
                     o[0] = c[4 * p]; o[1] = c[4 * p + 1]; o[2] = c[4 * p + 2]; o[3] = c[4 * p + 3];
                 }
-#endif
                 i += 64;
             }
         }
@@ -370,13 +354,9 @@ __device__ __forceinline__ bool huf_decode_stream_fs(const u32 tOff, const u32 n
             u32 d[16];
 #pragma unroll
             for (u32 g = 0; g < 8; ++g) step(d[2 * g], d[2 * g + 1]);
-#if ZMI_LIT_EXPERIMENT == 3
-            if ((i & 1023u) == 0) { u32 x = 0; for (u32 g = 0; g < 16; ++g) x ^= d[g]; *(u32u*)(out + i) = x; }
-#else
             u32u* o = (u32u*)(out + i);
 #pragma unroll
             for (u32 g = 0; g < 16; ++g) o[g] = d[g];
-#endif
             i += 64;
         }
         while (i + 8 <= n) {
@@ -909,7 +889,7 @@ __global__ __launch_bounds__(256) void decode_literals_sync_kernel(const u8* __r
 //   selfsync (256 lanes per block): 0.15 ms up to 256 blocks, 0.25 ms per 1000 blocks beyond.
 // mode: 0 = choose by block count, 1 = serial, 2 = self-synchronising, 3 = compact.
 void launch_decode_literals(const u8* src, u8* out, u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks, u32* status,
-                            u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream)
+                            u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream, StageHook hook)
 {
     if (mode == 0) {
         static int cus[64] = {};                     // per device
@@ -927,11 +907,14 @@ void launch_decode_literals(const u8* src, u8* out, u8* scratch, const FrameDesc
         int dev = 0; (void)hipGetDevice(&dev);
         if (!attrSet[dev & 63]) { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(decode_literals_sync_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)sizeof(SyncLds)); attrSet[dev & 63] = true; }
         hipLaunchKernelGGL(decode_literals_sync_kernel, dim3(nBlocks), dim3(256), sizeof(SyncLds), stream, src, out, scratch, frames, blocks, nBlocks, status, dictFull, di);
+        hook("decode_literals");
         return;
     }
     if (mode == 3) hipLaunchKernelGGL(decode_literals_compact_kernel, dim3((nBlocks + kQuadsC - 1) / kQuadsC), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, slowFlags, dictFull, di);
     else           hipLaunchKernelGGL(decode_literals_kernel, dim3((nBlocks + kQuads - 1) / kQuads), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, slowFlags, dictFull, di);
+    hook("decode_literals");
     hipLaunchKernelGGL(decode_literals_slow_kernel, dim3(nBlocks), dim3(64), 0, stream, src, out, scratch, frames, blocks, nBlocks, status, (const u8*)slowFlags, dictFull, di);
+    hook("decode_literals_slow");
 }
 
 } // namespace zmi

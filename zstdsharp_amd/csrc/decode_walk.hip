@@ -325,8 +325,10 @@ __global__ __launch_bounds__(64) void block_link_kernel(FrameDesc* __restrict__ 
         if (B.litType == 2) { lastHuf = bi; B.hufSrc = bi; }
         else if (B.litType == 3) { B.hufSrc = lastHuf; if (lastHuf == kNoBlock) err = kErrDictionaryCorrupted; }     // U/ZstdDecompressBlock.cs:197-207
         if (B.litType >= 2) {
-            if (B.litSize > F.dstSize - litAcc) err = err ? err : (u32)kErrCorruption;
-            B.litRel = litAcc; litAcc += B.litSize;
+            // (the frame's literal scratch is dstSize long: a block that does not fit takes none of it, so the bound holds for the
+            //  blocks behind it whatever later kernels do with the frame)
+            if (B.litSize > F.dstSize - litAcc) { err = err ? err : (u32)kErrCorruption; B.litRel = 0; }
+            else { B.litRel = litAcc; litAcc += B.litSize; }
         }
         if (B.nbSeq) {
             hasSeq = 1;

@@ -52,7 +52,7 @@ __global__ __launch_bounds__(256) void gather_kernel(const u8* __restrict__ src,
                                                      u8* __restrict__ dst, u64 dstCapacity, u32 chunkBytes)
 {
     const u32 c = blockIdx.x, tid = threadIdx.x;
-    const ChunkMeta m = meta[c];
+    const ChunkMeta m = meta_checked(meta[c]);
     const u64 off = offsets[c];
     if (off + m.outSize > dstCapacity) return;           // host reports dstSize_tooSmall from the scanned total
     const u8* slot = slots + (u64)c * kSlotStride;

@@ -275,10 +275,11 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
 {
     __shared__ HufBuildLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const u32 litSize = meta[c].litSize, nbSeqIn = meta[c].nbSeq;
+    const ChunkMeta m0 = meta_checked(meta[c]);
+    const u32 litSize = m0.litSize, nbSeqIn = m0.nbSeq;
     HufWork* __restrict__ W = reinterpret_cast<HufWork*>(slots + (u64)c * kSlotStride);
     // (a chunk without sequences never copied its literals: they are its source bytes, lz_fast.hip)
-    const u8* __restrict__ lit = meta[c].litFromSrc ? src + (u64)c * chunkBytes : lits + (u64)c * kLitStride;
+    const u8* __restrict__ lit = m0.litFromSrc ? src + (u64)c * chunkBytes : lits + (u64)c * kLitStride;
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
@@ -410,7 +411,7 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
 {
     __shared__ HufTreeLds L;
     const u32 c = blockIdx.x, lane = threadIdx.x, tid = lane;
-    ChunkMeta m = meta[c];
+    ChunkMeta m = meta_checked(meta[c]);
     const u32 litSize = m.litSize;
     const u32 lhSizeRaw = 1 + (litSize > 31) + (litSize > 4095);
     const HufWork* __restrict__ W = reinterpret_cast<const HufWork*>(slots + (u64)c * kSlotStride);
@@ -592,7 +593,7 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
 {
     __shared__ HufEncLds L;
     const u32 c = blockIdx.x, tid = threadIdx.x, lane = lane_id(), wave = wave_id();
-    const ChunkMeta m = meta[c];
+    const ChunkMeta m = meta_checked(meta[c]);
     const u32 litSize = m.litSize;
     const u8* __restrict__ lit = m.litFromSrc ? src + (u64)c * chunkBytes : lits + (u64)c * kLitStride;
     u8* __restrict__ body = slots + (u64)c * kSlotStride + m.fhSize + 3;      // block body starts after frame + block header
@@ -698,10 +699,12 @@ __global__ __launch_bounds__(256) void huf_encode_kernel(const u8* __restrict__ 
 }
 
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
-                      hipStream_t stream)
+                      hipStream_t stream, StageHook hook)
 {
     hipLaunchKernelGGL(huf_hist_kernel, dim3(nChunks), dim3(256), 0, stream, lits, meta, slots, rawLiterals, src, chunkBytes);
+    hook("huf_hist");
     hipLaunchKernelGGL(huf_tree_kernel, dim3(nChunks), dim3(64), 0, stream, meta, tables, slots, rawLiterals);
+    hook("huf_tree");
 }
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, const u8* src, u32 chunkBytes, hipStream_t stream)

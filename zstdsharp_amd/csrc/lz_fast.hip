@@ -804,7 +804,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     // `frameBlocks` consecutive chunks the blocks of ONE frame, and a block's history is the input in front of it — up to
     // `hist` bytes, as far back as its frame reaches — staged in the same place a dictionary's tail would be.
     const u32 cb = DICT ? chunkBytes : kChunkSize;
-    const u32 hist = DICT ? kChunkSize - chunkBytes : 0u;
+    const u32 hist = DICT ? kChunkSize - ((chunkBytes + kTilePos - 1) & ~(kTilePos - 1)) : 0u;      // (chunks below a tile: ZSTD_c_windowLog 10, 11)
     const u64 base = (u64)c * cb;
     const u8* __restrict__ in = src + base;
     const u32 bf = ((DICT || FAR) && frameBlocks) ? c % frameBlocks : 0u;               // block index inside its frame
@@ -1463,8 +1463,8 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         if ((DICT || FAR) && frameBlocks) {   // only a frame's first block carries the frame header, sized for the whole frame's content
             const u64 fStart = base - (u64)bf * cb, fMax = (u64)frameBlocks * cb;
             const u64 fLen = (srcSize - fStart) < fMax ? (srcSize - fStart) : fMax;
-            m.fhSize = bf == 0 ? frame_header_size64(fLen) + fhExtra : 0u;
-        } else m.fhSize = frame_header_size(nData) + fhExtra;      // fhExtra: bytes of the dictID field (formatted dictionary), else 0
+            m.fhSize = bf == 0 ? ((fhExtra >> 8) ? 6u : frame_header_size64(fLen)) + (fhExtra & 7u) : 0u;
+        } else m.fhSize = ((fhExtra >> 8) ? 6u : frame_header_size(nData)) + (fhExtra & 7u);      // fhExtra: bytes of the dictID field (formatted dictionary), else 0; bit 8: window descriptor instead of a content size (magic, descriptor, window byte)
         m.litFromSrc = deferred ? 1u : 0u;       // (then nbSeq = 0 and litBase = nData: the literals are the chunk itself)
         m.regionCursor = regionCursor;
         meta[c] = m;
@@ -1495,7 +1495,7 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
     const u32 rc = meta[c].regionCursor;
     // geometry as in lz_kernel
     const u32 cb = DICT ? chunkBytes : kChunkSize;
-    const u32 hist = DICT ? kChunkSize - chunkBytes : 0u;
+    const u32 hist = DICT ? kChunkSize - ((chunkBytes + kTilePos - 1) & ~(kTilePos - 1)) : 0u;
     const u64 base = (u64)c * cb;
     const u8* __restrict__ in = src + base;
     const u32 bf = (DICT && frameBlocks) ? c % frameBlocks : 0u;
@@ -1558,9 +1558,14 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
 size_t lz_fast_lds_bytes() { return sizeof(LzLds); }
 
 // How much is there for a match finder to find?  The input in groups of groupBytes; per group, tilesPerGroup tiles of 4 KiB spread
-// evenly over it; per tile, the positions whose 6 bytes' hash was seen earlier in the same tile with the same tag and the same first
-// four bytes (what the fast finder's first-occurrence table would offer them) are counted into out[group].  Text: several hundred per
-// tile; Zipf or random bytes: a handful.  (One workgroup per tile, reads 4 KiB.)
+// evenly over it; per tile, two counts go into out[group]: (A) the positions whose 6 bytes' hash was seen earlier in the same tile
+// with the same tag and the same first four bytes (what the fast finder's first-occurrence table would offer them), and (B) the
+// positions of the 60 KiB in front of the tile — the reach of the history the levels >= 3 stage beside a block — that agree with
+// a position of the tile on 8 bytes: redundancy that only shows at a distance (repeated incompressible records, duplicate pages)
+// repeats nothing inside 4 KiB.  Text: several hundred per tile; Zipf or random bytes: a handful (an 8-byte agreement between
+// independent Zipf(1.1) strings has probability 2e-10; the 6-byte hash with its tag lets a hundredth of a pair per tile through).
+// (One workgroup per tile, reads 64 KiB: an eighth of the input at eight tiles per 4 MiB.)
+constexpr u32 kProbeBack = 60u << 10;
 __global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ src, u64 srcSize, u64 groupBytes, u32 tilesPerGroup, u32* __restrict__ out)
 {
     __shared__ u32 firstSeen[1u << kHashLog];
@@ -1589,6 +1594,15 @@ __global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ sr
             if (fq < q && (f & 0xFFFFu) == htag(h[j]) && readLE32(in + fq) == readLE32(in + q)) ++cnt;
         }
     }
+    // (B) the window in front of the tile against the tile's table
+    const u32 back = avail < 16 ? 0u : off < kProbeBack ? (u32)off : kProbeBack;       // (the last read of the window reaches 7 bytes into the tile)
+    const u8* __restrict__ win = in - back;
+    for (u32 p = tid; p < back; p += 256) {
+        const u64 w = readLE64(win + p);
+        const u32 hp = hash6p(w);
+        const u32 f = firstSeen[hidx(hp)];
+        if ((f & 0xFFFFu) == htag(hp) && f != 0xFFFFFFFFu && readLE64(in + (f >> 16)) == w) ++cnt;
+    }
     cnt = wave_sum(cnt);
     if (lane_id() == 0 && cnt) atomicAdd(&out[g], cnt);
 }
@@ -1609,7 +1623,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook)
 {
     // the region parse of dense chunks: a second kernel behind a work list (see lz_region_kernel), inlined for the others
     constexpr bool kSplit = (MODE == 0 && !DICT && !FAR) || MODE == 2;
@@ -1627,36 +1641,40 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
     //  still hands workgroups to CUs as they free up, which is what balances chunks of unequal cost.  Everything else: a workgroup per chunk)
     const u32 grid = (MODE == 0 && !DICT && !FAR && nChunks > 4096) ? 4096u : nChunks;
     hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, cand ? chain : nullptr, cand ? regionList : nullptr, nChunks);
-    if constexpr (kSplit) if (cand)                        // the dense chunks' rest: 256 workgroups (one per CU) walk the list
+    hook("lz_fast");
+    if constexpr (kSplit) if (cand) {                      // the dense chunks' rest: 256 workgroups (one per CU) walk the list
         hipLaunchKernelGGL((lz_region_kernel<MODE, DICT>), dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, chain, regionList,
                            prefix, prefixLen, chunkBytes, frameBlocks, hcDepth);
+        hook("lz_region");
+    }
 }
 
 // finder: 0 = fast, 1 = dual (8-byte + 5-byte hashes), 2 = dual + lazy deferral.  (A 4-byte short hash, the reference's
 // minMatch at levels 4+, was measured and lost ratio on every corpus tried: far 4-byte matches cost more than literals.)
 // prefix/prefixLen: the dictionary bytes every chunk sees as history (null/0 without one); chunkBytes = 64 KiB minus prefixLen
 // rounded up to whole 4 KiB tiles.  frameBlocks > 0: cross-chunk history instead (no dictionary): `frameBlocks` chunks of chunkBytes
-// form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.
+// form one frame and each sees up to 64 KiB - chunkBytes of the input in front of it.  chunkBytes < 64 KiB with neither: independent
+// frames of chunkBytes each (ZSTD_c_windowLog 10 .. 15: a frame is its own window), on the same instantiation with an empty history.
 // cand / regionList (null: off): workspace of the region parse, 65536 u16 per chunk and 1 + nChunks u32.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook)
 {
     if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
-        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, nullptr, 0, stream);
+        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, nullptr, 0, stream, hook);
         return;
     }
-    if (chunkBytes >= kChunkSize || (prefixLen == 0 && frameBlocks == 0)) {
+    if (chunkBytes >= kChunkSize) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook); break;
     }
 }
 

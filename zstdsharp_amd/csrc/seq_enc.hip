@@ -173,7 +173,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     const bool live = c < nChunks;        // (a wave without a chunk still meets the workgroup's barriers below)
     SeqWaveLds& W = Ws[wave];
     ChunkMeta m = {};
-    if (live) m = meta[c];
+    if (live) m = meta_checked(meta[c]);
     const u32 nbSeq = m.nbSeq, n = m.srcSize;
     // Multi-block frames (row f-1): chunk c is block bf of frame c / frameBlocks.  A later block never relies on the repcodes the
     // blocks before it leave behind — whether one of them ends up stored raw (and so leaves the decoder's history untouched,
@@ -305,6 +305,10 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
         const u32 chainSeq = (wave == 0 && lane < 12) ? sBatchSeq[cw] : 0u;
         u32 state = 0;
         u32 carry = 0, carryBits = 0, outWords = 0;
+        // room for the bitstream in the chunk's slot: a stream that does not fit is longer than the block it encodes (sequences no
+        // finder can produce) — it is cut short and the block stored raw
+        const u32 roomWords = (kSlotStride - 64u - (m.fhSize + 3u + bodyTablesEnd)) >> 2;
+        bool ovf = false;
         for (u32 done = 0; done < maxSeq; done += 64) {
             const bool act = done < mySeq;                      // uniform per wave
             const u32 cnt = act ? (mySeq - done < 64 ? mySeq - done : 64) : 0;
@@ -389,9 +393,10 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
             const u32 total = carryBits + batchBits;
             const u32 fullWords = total >> 5;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
-            for (u32 i = lane; i < fullWords; i += 64) *(u32u*)(out + 4 * (outWords + i)) = W.tile[i];
+            if (outWords + fullWords > roomWords) ovf = true;          // (uniform)
+            if (!ovf) for (u32 i = lane; i < fullWords; i += 64) *(u32u*)(out + 4 * (outWords + i)) = W.tile[i];
             carry = W.tile[fullWords]; carryBits = total & 31;
-            outWords += fullWords;
+            if (!ovf) outWords += fullWords;
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier();
         }
         ZMI_ESTAMP(3);
@@ -411,6 +416,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
             bitstreamSize = 4 * outWords + nbytes;
         }
         bitstreamSize = uniform(bitstreamSize);
+        if (ovf) giveUp = true;
     }
 #ifdef ZMI_LZ_STAMPS
     if (lane == 0) for (int i = 0; i < 8; i++) atomicAdd(&g_sencStamps[i], stampAcc[i]);
@@ -424,18 +430,27 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     u32 cSize = (u32)(op - body);
     if (!giveUp && cSize >= n - ((n >> 6) + 2)) giveUp = true;                      // ZSTD_minGain
 
-    // ---- frame header (single segment, content size known), in front of the frame's first block ----
+    // ---- frame header in front of the frame's first block (ZSTD_writeFrameHeader, U/ZstdCompress.cs:4817-4929): single segment with
+    // the content size, or — ZSTD_c_contentSizeFlag = 0 (checksumFlag bit 1) — a window descriptor and no content size: the smallest
+    // power of two that holds the frame (>= 1 KiB), so that no offset and no block exceeds the declared window ----
     if (bf == 0) {
-        const u32 fcsCode = (frameLen >= 256) + (frameLen >= 65536 + 256) + (frameLen > 0xFFFFFFFFull);
         writeLE32(slot, 0xFD2FB528u);
         const u32 didCode = dictIdBytes == 4 ? 3u : dictIdBytes;          // dictID field of 0, 1, 2 or 4 bytes (U/ZstdCompress.cs:4843-4849, 4896-4918)
-        slot[4] = (u8)(didCode + ((checksumFlag ? 1u : 0u) << 2) + (1u << 5) + (fcsCode << 6));
-        for (u32 i = 0; i < dictIdBytes; i++) slot[5 + i] = (u8)(dictID >> (8 * i));
-        u8* const fcs = slot + 5 + dictIdBytes;
-        if (fcsCode == 0) fcs[0] = (u8)frameLen;
-        else if (fcsCode == 1) writeLE16(fcs, (u32)frameLen - 256);
-        else if (fcsCode == 2) writeLE32(fcs, (u32)frameLen);
-        else { writeLE32(fcs, (u32)frameLen); writeLE32(fcs + 4, (u32)(frameLen >> 32)); }
+        if (checksumFlag & 2u) {
+            u32 wl = 10; while (((u64)1 << wl) < frameLen) ++wl;
+            slot[4] = (u8)(didCode + ((checksumFlag & 1u) << 2));
+            slot[5] = (u8)((wl - 10) << 3);
+            for (u32 i = 0; i < dictIdBytes; i++) slot[6 + i] = (u8)(dictID >> (8 * i));
+        } else {
+            const u32 fcsCode = (frameLen >= 256) + (frameLen >= 65536 + 256) + (frameLen > 0xFFFFFFFFull);
+            slot[4] = (u8)(didCode + ((checksumFlag & 1u) << 2) + (1u << 5) + (fcsCode << 6));
+            for (u32 i = 0; i < dictIdBytes; i++) slot[5 + i] = (u8)(dictID >> (8 * i));
+            u8* const fcs = slot + 5 + dictIdBytes;
+            if (fcsCode == 0) fcs[0] = (u8)frameLen;
+            else if (fcsCode == 1) writeLE16(fcs, (u32)frameLen - 256);
+            else if (fcsCode == 2) writeLE32(fcs, (u32)frameLen);
+            else { writeLE32(fcs, (u32)frameLen); writeLE32(fcs + 4, (u32)(frameLen >> 32)); }
+        }
     }
     u8* const bh = slot + m.fhSize;
     const u32 lastBit = lastBlock ? 1u : 0u;                  // Last_Block (U/ZstdCompress.cs:4757-4760)
@@ -446,7 +461,7 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
         writeLE24(bh, lastBit + (2u << 1) + (cSize << 3));
         m.blockType = 2; m.bodySize = cSize;
     }
-    m.outSize = m.fhSize + 3 + cSize + ((checksumFlag && lastBlock) ? 4 : 0);
+    m.outSize = m.fhSize + 3 + cSize + (((checksumFlag & 1u) && lastBlock) ? 4 : 0);
     meta[c] = m;
 }
 

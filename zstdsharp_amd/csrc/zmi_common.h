@@ -140,6 +140,13 @@ struct SeqRec {
 enum : u32 { kStFrames = 0, kStErr = 1, kStTotalLo = 2, kStTotalHi = 3, kStUsable = 4, kStUnsized = 5, kStBlocks = 6, kStSeqLo = 8, kStSeqHi = 9,
              kStErrKeyLo = 10, kStErrKeyHi = 11, kStActualLo = 12, kStActualHi = 13, kStWords = 16 };
 
+// Stage timing (ZSTDMI_*_setProfiling): a launcher that issues several kernels marks the end of each on the context's timer, so
+// that a stage time is ONE kernel's duration (bench.py prices the slowest kernel against the HBM roof).  No-op when profiling is off.
+struct StageHook {
+    void (*fn)(void* self, const char* name) = nullptr; void* self = nullptr;
+    void operator()(const char* name) const { if (fn) fn(self, name); }
+};
+
 // error codes: U/ZSTD_ErrorCode.cs
 enum : u32 {
     kErrGeneric = 1, kErrPrefixUnknown = 10, kErrVersionUnsupported = 12, kErrFrameParameterUnsupported = 14,

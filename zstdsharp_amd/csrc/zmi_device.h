@@ -53,6 +53,17 @@ __device__ __forceinline__ void writeLE16(u8* p, u32 v) { p[0] = (u8)v; p[1] = (
 __device__ __forceinline__ void writeLE24(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); }
 __device__ __forceinline__ void writeLE32(u8* p, u32 v) { p[0] = (u8)v; p[1] = (u8)(v >> 8); p[2] = (u8)(v >> 16); p[3] = (u8)(v >> 24); }
 
+// What the entropy stage may rely on in a ChunkMeta whatever the match finder left there (a finder bug, or an experiment build
+// without its emit phase, must not turn into out-of-bounds addresses downstream): sizes inside the chunk's buffers; a record that
+// breaks them is taken as "no sequences".  Every consumer applies the same function, so all of them see the same chunk.
+__device__ __forceinline__ ChunkMeta meta_checked(ChunkMeta m)
+{
+    if (m.srcSize > kChunkSize) m.srcSize = kChunkSize;
+    if (m.nbSeq > kMaxSeq || m.litSize > m.srcSize) { m.nbSeq = 0; if (m.litSize > m.srcSize) m.litSize = m.srcSize; }
+    if (m.fhSize > 18) m.fhSize = 18;
+    return m;
+}
+
 // frame header size for a chunk of n bytes: magic + FHD + FCS, single-segment (U/ZstdCompress.cs:4817-4929)
 __host__ __device__ __forceinline__ u32 frame_header_size(u32 n) { return 4 + 1 + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : 4)); }
 __host__ __device__ __forceinline__ u32 frame_header_size64(u64 n) { return 4 + 1 + (n < 256 ? 1 : (n < 65536 + 256 ? 2 : (n <= 0xFFFFFFFFull ? 4 : 8))); }

@@ -18,10 +18,10 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook);
 void launch_lz_probe(const u8* src, u64 srcSize, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
-                      hipStream_t stream);
+                      hipStream_t stream, StageHook hook);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
                        u32 nChunks, const u8* src, u32 chunkBytes, hipStream_t stream);
 void launch_seq_encode(Seq* seqs, ChunkMeta* meta, u8* slots, u32 nChunks, u32 strategy, u32 checksumFlag, u32 resolveReps,
@@ -42,7 +42,7 @@ void launch_seq_decode(const u8* src, const FrameDesc* frames, BlockDesc* blocks
                        const u8* dictFull, const DictInfo* di, hipStream_t stream);
 void launch_block_offsets(FrameDesc* frames, BlockDesc* blocks, u32 nFrames, const DictInfo* di, u32 rescan, u64 dstCapacity, u32* status, hipStream_t stream);
 void launch_decode_literals(const u8* src, u8* out, u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks, u32* status,
-                            u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream);
+                            u8* slowFlags, u32 mode, const u8* dictFull, const DictInfo* di, hipStream_t stream, StageHook hook);
 void launch_place_literals(const u8* src, u8* out, const u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks,
                            const SeqRec* recs, const u32* status, hipStream_t stream);
 void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
@@ -63,7 +63,7 @@ template <class F> static size_t guarded(F f)
 
 namespace {
 
-constexpr int kMaxStages = 12;
+constexpr int kMaxStages = 24;
 
 struct DevBuf {
     void* p = nullptr; size_t cap = 0;
@@ -83,8 +83,10 @@ struct StageTimer {
     hipEvent_t ev[kMaxStages + 1] = {};
     const char* names[kMaxStages] = {};
     float ms[kMaxStages] = {};
-    int n = 0; bool created = false;
-    void begin(hipStream_t s) { n = 0; if (!enabled) return; if (!created) { for (auto& e : ev) (void)hipEventCreate(&e); created = true; } (void)hipEventRecord(ev[0], s); }
+    int n = 0; bool created = false; hipStream_t stream = nullptr;
+    static void hook_fn(void* self, const char* name) { StageTimer* t = (StageTimer*)self; t->mark(name, t->stream); }
+    StageHook hook() { StageHook h; if (enabled) { h.fn = hook_fn; h.self = this; } return h; }
+    void begin(hipStream_t s) { n = 0; stream = s; if (!enabled) return; if (!created) { for (auto& e : ev) (void)hipEventCreate(&e); created = true; } (void)hipEventRecord(ev[0], s); }
     void mark(const char* name, hipStream_t s) { if (!enabled || n >= kMaxStages) return; names[n] = name; (void)hipEventRecord(ev[n + 1], s); n++; }
     void finish() { if (!enabled) return; for (int i = 0; i < n; i++) { float t = 0; (void)hipEventElapsedTime(&t, ev[i], ev[i + 1]); ms[i] = t; } }
     void destroy() { if (created) for (auto& e : ev) (void)hipEventDestroy(e); created = false; }
@@ -104,11 +106,19 @@ bool is_formatted_dictionary(const u8* p, size_t n)
     return n >= 8 && ((u32)p[0] | ((u32)p[1] << 8) | ((u32)p[2] << 16) | ((u32)p[3] << 24)) == 0xEC30A437u;
 }
 
+// devices the kernels can run on: the leading run of gfx950 agents (device ordinals stay HIP's, so a context's device index means
+// the same thing to the caller's runtime; the code objects in this library are gfx950 only)
 int device_count()
 {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
-    return n;
+    int ok = 0;
+    for (; ok < n; ++ok) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, ok) != hipSuccess) { (void)hipGetLastError(); break; }
+        if (strncmp(p.gcnArchName, "gfx950", 6) != 0) break;
+    }
+    return ok;
 }
 
 } // namespace
@@ -201,13 +211,14 @@ static size_t dctx_bind(ZSTD_DCtx* d)
 // ZSTD_compressCCtx, the level alone with default frame parameters and no dictionary (U/ZstdCompress.cs:5751-5776:
 // compress_usingDict(NULL) builds its parameters from the level and leaves the context's requested ones untouched).
 struct CallParams {
-    int level = 3, checksumFlag = 0, dictIDFlag = 1, strategy = 0, targetLength = 0, windowLog = 0, searchLog = 0;
+    int level = 3, checksumFlag = 0, contentSizeFlag = 1, dictIDFlag = 1, strategy = 0, targetLength = 0, windowLog = 0, searchLog = 0;
+    int minMatch = 0, chainLog = 0;     // accepted by the setters only at the value the kernels implement for the level/strategy in force THEN: checked again per call
     bool useDict = true;
 };
 static CallParams sticky_params(const ZSTD_CCtx* c)
 {
-    CallParams p; p.level = c->level; p.checksumFlag = c->checksumFlag; p.dictIDFlag = c->dictIDFlag;
-    p.strategy = c->strategy; p.targetLength = c->targetLength; p.windowLog = c->windowLog; p.searchLog = c->searchLog; p.useDict = true;
+    CallParams p; p.level = c->level; p.checksumFlag = c->checksumFlag; p.contentSizeFlag = c->contentSizeFlag; p.dictIDFlag = c->dictIDFlag;
+    p.strategy = c->strategy; p.targetLength = c->targetLength; p.windowLog = c->windowLog; p.searchLog = c->searchLog; p.minMatch = c->minMatch; p.chainLog = c->chainLog; p.useDict = true;
     return p;
 }
 
@@ -282,7 +293,8 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
     if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
         u8 f[13]; size_t n = 0;
         f[n++] = 0x28; f[n++] = 0xB5; f[n++] = 0x2F; f[n++] = 0xFD;
-        f[n++] = (u8)((cp.checksumFlag ? 4 : 0) | 0x20); f[n++] = 0;
+        if (cp.contentSizeFlag) { f[n++] = (u8)((cp.checksumFlag ? 4 : 0) | 0x20); f[n++] = 0; }
+        else { f[n++] = (u8)(cp.checksumFlag ? 4 : 0); f[n++] = (u8)(((cp.windowLog >= 10 ? cp.windowLog : 10) - 10) << 3); }   // window descriptor, no content size
         f[n++] = 1; f[n++] = 0; f[n++] = 0;
         if (cp.checksumFlag) { f[n++] = 0x99; f[n++] = 0xE9; f[n++] = 0xD8; f[n++] = 0x51; }   // XXH64("") low 32 bits = 0x51D8E999
         if (dstCapacity < n) return ZERR(kErrDstSizeTooSmall);
@@ -293,6 +305,9 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
     if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
     const u32 prefixLen = cp.useDict ? dict_prefix_len(c, srcSize) : 0u;
     u32 chunkBytes = kChunkSize - round_tile(prefixLen);
+    // ZSTD_c_windowLog 10 .. 15: independent frames of 1 << windowLog bytes (the reference cuts blocks at the window size and lets
+    // no offset exceed it, U/ZstdCompress.cs:4690-4712, U/ZstdCompressInternal.cs:787-813; a frame that IS its own window does both)
+    if (cp.windowLog >= 10 && cp.windowLog < (int)kChunkLog && chunkBytes > (1u << cp.windowLog)) chunkBytes = 1u << cp.windowLog;
     // a formatted dictionary: its dictID in every frame header (unless ZSTD_c_dictIDFlag = 0), its repcodes in front of every frame
     const bool fmtDict = cp.useDict && c->dictFormatted;
     const u32 dictID = fmtDict ? c->info.dictID : 0u;
@@ -305,7 +320,9 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
     // match never reaches out of its frame and frames stay independent units for the decoder and for sharding).  Without a
     // dictionary only (a dictionary's tail takes the same place in LDS).
     u32 frameBlocks = 0;
-    if (prefixLen == 0 && srcSize > kChunkSize) {
+    // a frame never declares more than the window the caller asked for (its content size is its window)
+    const u32 frameBytes = (cp.windowLog >= (int)kChunkLog && cp.windowLog < 31 && ((u64)1 << cp.windowLog) < c->frameBytes) ? (1u << cp.windowLog) : c->frameBytes;
+    if (prefixLen == 0 && srcSize > kChunkSize && chunkBytes == kChunkSize && frameBytes > kChunkSize) {
         int hb = c->historyBytes;
         // by level: the doubleFast levels (3-4; 3 is the library's default level) stage 16 KiB of history per 48 KiB block (one
         // third more staging and hashing for three quarters of what 32 KiB buy), greedy and above 32 KiB per 32 KiB block
@@ -315,10 +332,10 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
             // finds far matches through its table (candidates in front of the block are verified against global memory, up to
             // 188 KiB back); the dual-hash finders' 16-bit tables cannot hold far positions, so their blocks shrink to
             // 64 KiB - hist and carry the hist bytes in front of them in LDS
-            const Resolved rf = resolve_call(cp, srcSize < c->frameBytes ? srcSize : c->frameBytes, c->frameBytes);
+            const Resolved rf = resolve_call(cp, srcSize < frameBytes ? srcSize : frameBytes, frameBytes);
             if (rf.finder == 0) chunkBytes = kChunkSize;
             else { const u32 histB = round_tile((size_t)hb) > (48u << 10) ? (48u << 10) : round_tile((size_t)hb); chunkBytes = kChunkSize - histB; }
-            frameBlocks = c->frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
+            frameBlocks = frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
             rs = rf;
         }
     }
@@ -344,11 +361,11 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes, rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, hcChains ? (u16*)((u8*)c->cand.p + cand_plane_bytes(passChunks)) : nullptr,
-                  regionParse ? (u32*)((u8*)c->cand.p + cand_plane_bytes(passChunks) * (hcChains ? 2 : 1)) : nullptr, hcDepth, s);      c->timer.mark("lz_fast", s);
-        launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s);        c->timer.mark("huf_build", s);
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes | (cp.contentSizeFlag ? 0u : 0x100u), rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, hcChains ? (u16*)((u8*)c->cand.p + cand_plane_bytes(passChunks)) : nullptr,
+                  regionParse ? (u32*)((u8*)c->cand.p + cand_plane_bytes(passChunks) * (hcChains ? 2 : 1)) : nullptr, hcDepth, s, c->timer.hook());
+        launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s, c->timer.hook());
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
-        launch_seq_encode(seqs, meta, slots, nChunks, strategy, cp.checksumFlag ? 1 : 0, 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, (cp.checksumFlag ? 1u : 0u) | (cp.contentSizeFlag ? 0u : 2u), 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
@@ -375,7 +392,7 @@ static void level_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t srcSi
     chunkBytes = kChunkSize; frameBlocks = 0;
     const int hb = (r0.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (r0.cp.strategy == kStratDfast ? (16 << 10) : (32 << 10)) : 0;
     if (hb <= 0 || srcSize <= kChunkSize) return;
-    const Resolved rf = resolve_call(cp, srcSize < c->frameBytes ? srcSize : c->frameBytes, c->frameBytes);
+    const Resolved rf = resolve_call(cp, srcSize < c->frameBytes ? srcSize : c->frameBytes, c->frameBytes);      // (the probe runs only when windowLog is left to the level)
     if (rf.finder != 0) chunkBytes = kChunkSize - round_tile((size_t)hb);
     frameBlocks = c->frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
 }
@@ -392,7 +409,13 @@ static void level_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t srcSi
 static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
 {
     bool first = true;
-    bool probe = srcSize >= (4u << 20) && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0;
+    if (cp.minMatch || cp.chainLog) {       // set under another level or strategy than the call runs with: refuse, never ignore
+        const CParams lv = get_cparams(cp.level, kChunkSize);
+        if (cp.minMatch && cp.minMatch != (int)kernel_min_match(cp.strategy ? (u32)cp.strategy : lv.strategy)) return ZERR(kErrParameterUnsupported);
+        if (cp.chainLog && cp.chainLog != (int)lv.chainLog) return ZERR(kErrParameterUnsupported);
+    }
+    // (a caller-set targetLength keeps the level's own path: at the fast strategy it means raw literals, which the sparse ranges must not inherit)
+    bool probe = srcSize >= (4u << 20) && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0 && cp.targetLength == 0;
     if (probe) {
         if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
         if (cp.useDict && dict_prefix_len(c, srcSize)) probe = false;
@@ -472,20 +495,19 @@ size_t ZSTD_CCtx_setParameter(ZSTD_CCtx* c, int param, int value)
         c->level = value == 0 ? 3 : value;
         return c->level >= 0 ? (size_t)c->level : 0;        /* a size_t cannot carry a negative level (U/ZstdCompress.cs:899-905) */
     case ZSTD_c_checksumFlag:    if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound); c->checksumFlag = value; return (size_t)value;
-    case ZSTD_c_contentSizeFlag: if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound);
-                                 if (value == 0) return ZERR(kErrParameterUnsupported);   /* the GPU framing needs sized frames */
+    case ZSTD_c_contentSizeFlag: if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound);   /* 0: window descriptor instead of the content size */
                                  c->contentSizeFlag = value; return (size_t)value;
     case ZSTD_c_dictIDFlag:      if (value < 0 || value > 1) return ZERR(kErrParameterOutOfBound); c->dictIDFlag = value; return (size_t)value;
     case ZSTD_c_nbWorkers:       if (value != 0) return ZERR(kErrParameterUnsupported); return 0;   /* as U/ZstdCompress.cs:1064-1072 */
     case ZSTD_c_windowLog:       if (value != 0 && (value < 10 || value > 31)) return ZERR(kErrParameterOutOfBound);
-                                 if (value != 0 && value < (int)kChunkLog) return ZERR(kErrParameterUnsupported);   /* frames are 64 KiB single-segment */
-                                 c->windowLog = value; return (size_t)value;
+                                 c->windowLog = value; return (size_t)value;            /* 10 .. 15: frames of 1 << windowLog bytes; 17+: frames of at most that */
     // Match-finder parameters (bounds: ZSTD_cParam_getBounds, U/ZstdCompress.cs:444-700).  0 = "from the level".  A value the
     // kernels implement is accepted and stored; any other value within bounds is parameter_unsupported, never silently ignored.
     case ZSTD_c_strategy:        // every strategy maps onto one of the three finders (resolve_call)
         if (value < 0 || value > 9) return ZERR(kErrParameterOutOfBound);
         c->strategy = value; return (size_t)value;
-    case ZSTD_c_targetLength:    // fast strategy: acceleration (the probing stride) and, when > 0, raw literals; otherwise no effect on the finders
+    case ZSTD_c_targetLength:    // fast strategy: acceleration (the probing stride) and, when > 0, raw literals; the other strategies' finders have no
+                                 // counterpart of it (accepted and unused there, as the reference's greedy/lazy levels 5-12 ignore it: U/ZstdLazy.cs)
         if (value < 0 || value > (1 << 17)) return ZERR(kErrParameterOutOfBound);
         c->targetLength = value; return (size_t)value;
     case ZSTD_c_hashLog:         // the LDS tables have 2^13 buckets whatever the level's row says
@@ -859,8 +881,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     SeqRec* recs = (SeqRec*)d->recs.p;
     launch_seq_decode(d_src, frames, blocks, nBlocks, recs, status, dictFull, dinfo, s);            d->timer.mark("seq_decode", s);
     launch_block_offsets(frames, blocks, nFrames, dinfo, nUnsized ? 1u : 0u, dstCapacity, status, s);  d->timer.mark("block_offsets", s);
-    launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s);
-    d->timer.mark("decode_literals", s);
+    launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s, d->timer.hook());
     launch_place_literals(d_src, d_dst, (const u8*)d->scratch.p, frames, blocks, nBlocks, recs, status, s);    d->timer.mark("place_literals", s);
     launch_exec_matches(d_src, d_dst, frames, blocks, nFrames, recs, status, dictContent, dictContentSize, s);  d->timer.mark("exec_matches", s);
     if (!read_status(st)) return ZERR(kErrGeneric);
@@ -1113,7 +1134,7 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (nbSeq) (void)hipMemcpyAsync(c->seqs.p, seqs, nbSeq * sizeof(Seq), hipMemcpyHostToDevice, s);
     if (litSize) (void)hipMemcpyAsync(c->lits.p, lits, litSize, hipMemcpyHostToDevice, s);
     (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
-    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, 0, nullptr, 0, s);
+    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, 0, nullptr, 0, s, StageHook());
     launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, nullptr, 0, s);
     { const u32 plainReps[3] = { 1, 4, 8 };
       const Resolved rs = resolve_call(sticky_params(c), srcSize, kChunkSize);
@@ -1125,6 +1146,25 @@ size_t ZSTDMI_debugEntropyBlock(ZSTD_CCtx* c, void* dst, size_t dstCapacity, con
     if (hipMemcpy(dst, (u8*)c->slots.p + m.fhSize + 3, m.bodySize, hipMemcpyDeviceToHost) != hipSuccess) return ZERR(kErrGeneric);
     c->lastChunks = 1;
     return m.bodySize;
+}
+
+size_t ZSTDMI_debugPoisonedChunk(ZSTD_CCtx* c, unsigned nbSeq, unsigned litSize, unsigned srcSize, unsigned fill)
+{
+    size_t e = cctx_bind(c); if (isErr(e)) return e;
+    if (!cctx_workspace(c, 1)) return ZERR(kErrMemoryAllocation);
+    hipStream_t s = c->stream;
+    ChunkMeta m = {}; m.srcSize = srcSize; m.nbSeq = nbSeq; m.litSize = litSize; m.fhSize = 7;
+    (void)hipMemsetAsync(c->seqs.p, (int)(fill & 0xFF), (size_t)kMaxSeq * sizeof(Seq), s);
+    (void)hipMemsetAsync(c->lits.p, (int)(fill & 0xFF), kLitStride, s);
+    (void)hipMemcpyAsync(c->meta.p, &m, sizeof m, hipMemcpyHostToDevice, s);
+    launch_huf_build((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, 1, 0, (const u8*)c->lits.p, kChunkSize, s, StageHook());
+    launch_huf_encode((u8*)c->lits.p, (ChunkMeta*)c->meta.p, (HufTable*)c->tables.p, (u8*)c->slots.p, nullptr, nullptr, 0, 1, (const u8*)c->lits.p, kChunkSize, s);
+    { const u32 plainReps[3] = { 1, 4, 8 };
+      launch_seq_encode((Seq*)c->seqs.p, (ChunkMeta*)c->meta.p, (u8*)c->slots.p, 1, 1, 0, 1, 0, 0, plainReps, 0, kChunkSize, srcSize < kChunkSize ? srcSize : kChunkSize, s); }
+    if (hipMemcpyAsync(&m, c->meta.p, sizeof m, hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+    if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    c->lastChunks = 0;
+    return m.outSize;
 }
 
 // ---------------- entry points whose host-side containers may throw: guarded (see guarded()) ----------------

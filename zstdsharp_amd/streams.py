@@ -102,6 +102,9 @@ class DecompressionStream:
         self._leaveOpen = leaveOpen
         self._disposed = False
 
+    def SetParameter(self, parameter, value):                 # S/DecompressionStream.cs:48-52
+        self.decompressor.SetParameter(parameter, value)
+
     def LoadDictionary(self, dict_bytes):                     # S/DecompressionStream.cs:58-62
         self.decompressor.LoadDictionary(dict_bytes)
 
