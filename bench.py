@@ -57,7 +57,8 @@ STAGE_KERNEL = {"compress/lz_fast": ("lz_kernel",), "compress/lz_region": ("lz_r
                 "decompress/decode_literals": ("decode_literals_compact_kernel", "decode_literals_kernel", "decode_literals_sync_kernel"),
                 "decompress/decode_literals_slow": ("decode_literals_slow_kernel",),
                 "decompress/seq_decode": ("seq_decode_kernel",), "decompress/place_literals": ("place_literals_kernel",),
-                "decompress/exec_matches": ("exec_matches_kernel", "origin_jump_kernel"), "decompress/frame_walk": ("walk_segments_kernel",),
+                "decompress/exec_matches": ("exec_matches_kernel",), "decompress/origin_init": ("origin_init_kernel",),
+                "decompress/origin_jump": ("origin_jump_kernel",), "decompress/origin_gather": ("origin_gather_kernel",), "decompress/frame_walk": ("walk_segments_kernel",),
                 "decompress/block_prepass": ("block_parse_kernel",), "decompress/block_offsets": ("block_offsets_kernel",)}
 
 

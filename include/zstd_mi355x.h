@@ -143,6 +143,11 @@ size_t ZSTDMI_CCtx_setParser(ZSTD_CCtx* cctx, unsigned mode);
  * 3 = serial with compact tables (2 KiB + pair table per frame: twice the frames in flight) */
 size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* dctx, unsigned mode);
 
+/* match execution of long frames (the reference's Compressor writes ONE frame per call, U/ZstdCompress.cs:4690-4815): 0 = by cost
+ * (default: a frame whose ordered one-wave walk would take longer than a parallel sweep of all such frames is resolved by origin
+ * pointers — decode_origin.hip —, the others are walked), 1 = always the walk, 2 = origin pointers for every frame of 1 MiB or more */
+size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* dctx, unsigned mode);
+
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
 size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);
 size_t ZSTDMI_decompressDevice(ZSTD_DCtx* dctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);

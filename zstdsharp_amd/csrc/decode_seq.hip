@@ -224,14 +224,11 @@ __device__ __forceinline__ void seq_fields_batch(const SeqLds& L, u32 buf, u32 s
             }
         }
     }
-    const u32 inclOut = wave_scan_incl(ll + ml), inclLit = wave_scan_incl(ll);
-    const u32 totalOut = read_lane(inclOut, 63), totalLit = read_lane(inclLit, 63);
+    const u32 totalOut = wave_sum(ll + ml), totalLit = wave_sum(ll);
     if (totalLit > litSize - S.litUsed) { S.err = kErrCorruption; return; }
     if (totalOut > 0xFFFFFFFFu - S.outBase - litSize) { S.err = kErrCorruption; return; }     // (no valid block regenerates 4 GiB)
-    if (have) {
-        SeqRec r; r.off = off; r.llTag = ll | (tag << 30); r.ml = ml; r.pos = S.outBase + inclOut - ll - ml;
-        rec[base + lane] = r;
-    }
+    if (ballot(have && !tag && off > kRecOffMax)) { S.err = kErrWindowTooLarge; return; }      // beyond what a record holds (windows above 512 MiB)
+    if (have) rec[base + lane] = rec_pack(ll, ml, off, tag);
     S.s0 = s0; S.s1 = s1; S.s2 = s2; S.outBase += totalOut; S.litUsed += totalLit;
 }
 
@@ -450,19 +447,20 @@ __global__ __launch_bounds__(64) void place_literals_kernel(const u8* __restrict
     else rleByte = src[B.srcOff + B.lhSize];
     u32 litPos = 0, outEnd = 0;
     const SeqRec* __restrict__ const rec = recs + B.seqBase;
-    SeqRec rNext; rNext.off = 1; rNext.llTag = 0; rNext.ml = 0; rNext.pos = 0;
+    SeqRec rNext; rNext.lo = 0; rNext.hi = 0;
     if (lane < nbSeq) rNext = rec[lane];                        // records come one batch ahead
     for (u32 base = 0; base < nbSeq; base += 64) {
         const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
         const bool have = lane < cnt;
-        u32 ll = 0, ml = 0, pos = 0;
         const SeqRec r = rNext;
         if (base + 64 + lane < nbSeq) rNext = rec[base + 64 + lane];
-        if (have) { ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; }
+        SeqLane q;
+        const u32 outNext = seq_batch(r, have, 1, 1, 1, outEnd, q);     // (offsets are of no interest here)
+        const u32 ll = q.ll, pos = q.pos;
         const u32 inclLit = wave_scan_incl(ll);
         const u32 totalLit = read_lane(inclLit, 63);
         const u32 sLit = litPos + inclLit - ll;
-        outEnd = read_lane(pos + ll + ml, cnt - 1);
+        outEnd = outNext;
         // literals: short runs by their own lane; long runs are cut into 16-byte pieces (the last one overlapping the one before,
         // so every piece is whole) and ALL pieces of the batch are dealt to the lanes round-robin, four in flight per lane: the
         // copy is paced by bandwidth, not by one load-store round trip per run
@@ -526,13 +524,15 @@ __global__ __launch_bounds__(64) void exec_matches_kernel(const u8* __restrict__
     if (f >= nFrames || status[kStErr]) return;
     const FrameDesc& F = frames[f];
     if (F.bad || !(F.hasSeq || F.checksum)) return;
+    const bool viaOrigin = uniform(F.viaOrigin) != 0;           // its matches are in place already (decode_origin.hip): the checksum is what is left
+    if (viaOrigin && !F.checksum) return;
     u8* const fout = out + F.dstOff;
     const u32 first = uniform(F.firstBlock), nb = uniform(F.nbBlocks);
 #ifdef ZMI_LZ_STAMPS
     unsigned long long stampAcc[8] = {0,0,0,0,0,0,0,0}; unsigned long long stampLast = __builtin_amdgcn_s_memtime();
 #endif
     u32 err = 0, errBlock = first;
-    for (u32 k = 0; k < nb && !err && F.hasSeq; ++k) {
+    for (u32 k = 0; k < nb && !err && F.hasSeq && !viaOrigin; ++k) {
         const BlockDesc& B = blocks[first + k];
         const u32 nbSeq = uniform(B.type == 2 ? B.nbSeq : 0u);
         if (!nbSeq) continue;
@@ -541,19 +541,17 @@ __global__ __launch_bounds__(64) void exec_matches_kernel(const u8* __restrict__
         const u32 in0 = uniform(B.repIn[0]), in1 = uniform(B.repIn[1]), in2 = uniform(B.repIn[2]);
         const SeqRec* __restrict__ const rec = recs + B.seqBase;
         // output of earlier blocks (other waves' literals included: kernel boundary) and of this wave so far is visible
-        SeqRec rNext; rNext.off = 1; rNext.llTag = 0; rNext.ml = 0; rNext.pos = 0;
+        SeqRec rNext; rNext.lo = 0; rNext.hi = 0;
         if (lane < nbSeq) rNext = rec[lane];                    // records come one batch ahead: their load rides under the copies
+        u32 outBase = 0;
         for (u32 base = 0; base < nbSeq; base += 64) {
             const u32 cnt = nbSeq - base < 64 ? nbSeq - base : 64;
             const bool have = lane < cnt;
-            u32 ll = 0, ml = 0, pos = 0, off = 1;
             const SeqRec r = rNext;
             if (base + 64 + lane < nbSeq) rNext = rec[base + 64 + lane];
-            if (have) {
-                ll = r.llTag & 0x3FFFFFFFu; ml = r.ml; pos = r.pos; off = r.off;
-                const u32 tag = r.llTag >> 30;
-                if (tag) { const u32 in = tag == 1 ? in0 : tag == 2 ? in1 : in2; off = in > off ? in - off : 1u; }
-            }
+            SeqLane q;
+            outBase = seq_batch(r, have, in0, in1, in2, outBase, q);
+            const u32 ll = q.ll, ml = q.ml, pos = q.pos, off = q.off;
             ZMI_SSTAMP(0);
             const u32 dMatch = pos + ll;                          // block-relative start of my match
             // offset beyond everything produced so far in this frame (+ the dictionary): corruption (:2218-2223)

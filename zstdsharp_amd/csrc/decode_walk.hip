@@ -67,7 +67,7 @@ __device__ inline void emit_frame(const u8* __restrict__ src, u64 pos, const Cha
                                   FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks)
 {
     FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.scratchOff = dstOff; f.srcSize = o.next - pos; f.dstSize = o.content;
-    f.firstBlock = firstBlock; f.nbBlocks = o.nbBlocks; f.unsized = o.unsized; f.checksum = o.checksum; f.bad = 0; f.hasSeq = 0;
+    f.firstBlock = firstBlock; f.nbBlocks = o.nbBlocks; f.unsized = o.unsized; f.checksum = o.checksum; f.bad = 0; f.hasSeq = 0; f.viaOrigin = 0; f.pad = 0; f.originOff = 0;
     frames[frameIdx] = f;
     u64 q = pos + o.hdrSize;
     for (u32 n = 0; n < o.nbBlocks; ++n) {
@@ -342,6 +342,9 @@ __global__ __launch_bounds__(64) void block_link_kernel(FrameDesc* __restrict__ 
         if (err) { B.err = err; report_error(status, bi, B.litType >= 2 && (err == kErrDictionaryCorrupted || B.litSize > F.dstSize) ? kStageLiterals : kStageSequences, err); }
     }
     F.hasSeq = hasSeq;
+    // long frames by size class: what the host decides the origin path from (decode_origin.hip); a frame without a content size counts with its bound
+    if (hasSeq && F.dstSize >= (1u << 20) && F.dstSize < (1ull << 31))
+        atomicAdd(reinterpret_cast<unsigned long long*>(status + kStBigBins) + highbit32((u32)(F.dstSize >> 20)), (unsigned long long)F.dstSize);
 }
 
 // ------------------------------------------------------------------------------------------------

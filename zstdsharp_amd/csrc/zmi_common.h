@@ -97,6 +97,9 @@ struct FrameDesc {      // one per frame found by the frame walk (U/ZstdDecompre
     u32 checksum;       // 1 = a 4-byte XXH64 checksum follows the last block
     u32 bad;            // 1 = some stage failed in this frame (its error is in the status words): later stages leave it alone
     u32 hasSeq;         // 1 = at least one block holds sequences (the ordered executor has work in this frame)
+    u32 viaOrigin;      // 1 = the frame's matches are resolved by the origin path (decode_origin.hip): exec_matches only checks its checksum
+    u32 pad;
+    u64 originOff;      // then: index of its first entry in the origin array
 };
 
 constexpr u32 kNoBlock   = 0xFFFFFFFFu;     // table source: nothing defined it (corruption, or the default where that is legal)
@@ -128,17 +131,24 @@ struct BlockDesc {
     u32 err;            // first error found in this block (0 = none)
 };
 
-// One decoded sequence (U/ZstdDecompressBlock.cs:2360-2484) as seq_decode leaves it for the executor.
-struct SeqRec {
-    u32 off;            // the match offset; when tag != 0 the number to subtract from repIn[tag - 1] (floor 1)
-    u32 llTag;          // litLength | tag << 30
-    u32 ml;             // matchLength
-    u32 pos;            // block-relative output position of the sequence's literals
-};
+// One decoded sequence (U/ZstdDecompressBlock.cs:2360-2484) as seq_decode leaves it for the executors, packed into 8 bytes:
+//   bits  0-16  litLength (<= 131071: LL_base[35] + 16 extra bits)
+//   bits 17-33  matchLength - 3 (<= 131071: ML_base[52] + 16 extra bits - 3)
+//   bits 34-63  bit 29 clear: the match offset (1 .. 2^29 - 1; a frame that reaches further back is refused with windowTooLarge);
+//               bit 29 set: a repcode left symbolic — bits 27-28 = i (1..3), bits 0-26 = d: the offset is max(repIn[i - 1] - d, 1)
+// The output position is not stored: consumers walk a block's records in order and carry the running sum of litLength + matchLength.
+struct SeqRec { u32 lo, hi; };
+constexpr u32 kRecOffMax = (1u << 29) - 1;
 
 // status words shared by the decoder's kernels and the host
 enum : u32 { kStFrames = 0, kStErr = 1, kStTotalLo = 2, kStTotalHi = 3, kStUsable = 4, kStUnsized = 5, kStBlocks = 6, kStSeqLo = 8, kStSeqHi = 9,
-             kStErrKeyLo = 10, kStErrKeyHi = 11, kStActualLo = 12, kStActualHi = 13, kStWords = 16 };
+             kStErrKeyLo = 10, kStErrKeyHi = 11, kStActualLo = 12, kStActualHi = 13,
+             kStOriginFrames = 14,      // frames the origin path took (origin_select_kernel)
+             kStOriginLo = 16, kStOriginHi = 17,        // entries of the origin array handed out so far (u64)
+             kStOriginChanged = 18,     // .. 18 + kOriginRounds: round r of the pointer jumping changed something
+             kStBigBins = 56,           // 12 x u64: content bytes of the frames with sequences by size class, bin k = [2^(20+k), 2^(21+k)) (bin 11: up to 2^31)
+             kStWords = 80 };
+constexpr u32 kOriginRounds = 36;
 
 // Stage timing (ZSTDMI_*_setProfiling): a launcher that issues several kernels marks the end of each on the context's timer, so
 // that a stage time is ONE kernel's duration (bench.py prices the slowest kernel against the HBM roof).  No-op when profiling is off.

@@ -461,6 +461,37 @@ struct SBits {
         return (u32)(v >> (u32)(q & 7)) & (0xFFFFFFFFu >> (32 - nb));
     }
 };
+// SeqRec (zmi_common.h) <-> fields.  unpack: tag 0 = `off` is the offset; tag 1..3 = the offset is max(repIn[tag - 1] - off, 1)
+__device__ __forceinline__ SeqRec rec_pack(u32 ll, u32 ml, u32 off, u32 tag)
+{
+    const u32 o30 = tag ? ((1u << 29) | (tag << 27) | (off & 0x7FFFFFFu)) : off;
+    const u64 v = (u64)ll | ((u64)(ml - 3u) << 17) | ((u64)o30 << 34);
+    SeqRec r; r.lo = (u32)v; r.hi = (u32)(v >> 32); return r;
+}
+__device__ __forceinline__ void rec_unpack(const SeqRec r, u32& ll, u32& ml, u32& off, u32& tag)
+{
+    const u64 v = (u64)r.lo | ((u64)r.hi << 32);
+    ll = (u32)v & 0x1FFFFu; ml = ((u32)(v >> 17) & 0x1FFFFu) + 3u;
+    const u32 o30 = r.hi >> 2;
+    tag = (o30 >> 29) ? (o30 >> 27) & 3u : 0u;
+    off = tag ? (o30 & 0x7FFFFFFu) : o30;
+}
+// one batch of up to 64 records of a block, one per lane, as the in-order consumers see it: lengths, the resolved offset, and the
+// block-relative position of the sequence's literals (`outBase` = the running sum before the batch; returns the sum after it).
+// `next` holds the batch's records (loaded one batch ahead by the caller).  Lanes >= cnt get ll = ml = 0.
+struct SeqLane { u32 ll, ml, off, pos; };
+__device__ __forceinline__ u32 seq_batch(const SeqRec r, bool have, u32 in0, u32 in1, u32 in2, u32 outBase, SeqLane& q)
+{
+    q.ll = 0; q.ml = 0; q.off = 1;
+    if (have) {
+        u32 tag; rec_unpack(r, q.ll, q.ml, q.off, tag);
+        if (tag) { const u32 in = tag == 1 ? in0 : tag == 2 ? in1 : in2; q.off = in > q.off ? in - q.off : 1u; }
+    }
+    const u32 incl = wave_scan_incl(q.ll + q.ml);
+    q.pos = outBase + incl - q.ll - q.ml;
+    return outBase + read_lane(incl, 63);
+}
+
 __device__ __forceinline__ u64 uniform64(u64 v) { return (u64)uniform((u32)v) | ((u64)uniform((u32)(v >> 32)) << 32); }
 
 } // namespace zmi

@@ -47,6 +47,9 @@ void launch_place_literals(const u8* src, u8* out, const u8* scratch, const Fram
                            const SeqRec* recs, const u32* status, hipStream_t stream);
 void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
                          const u8* dict, u32 dictSize, hipStream_t stream);
+void launch_origin_select(FrameDesc* frames, u32 nFrames, u64 minBytes, u32* list, u32 listCap, u64 originCap, u32* status, hipStream_t stream);
+void launch_origin_exec(const FrameDesc* frames, const BlockDesc* blocks, const u32* list, u32 listCap, u64 maxFrameBytes, const SeqRec* recs, u32* status,
+                        u32* origin, u8* out, const u8* dict, u32 dictSize, hipStream_t stream, StageHook hook);
 }
 
 using namespace zmi;
@@ -168,7 +171,8 @@ struct ZSTD_DCtx_s {
     int windowLogMax = 27;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
-    DevBuf frames, blocks, recs, status, scratch, walkWs, slowFlags, stageSrc, stageDst;
+    DevBuf frames, blocks, recs, status, scratch, walkWs, slowFlags, stageSrc, stageDst, origin, originList;
+    int originMode = 0;         // ZSTDMI_DCtx_setLongFrames: 0 = by cost (see decompress_device), 1 = never, 2 = every frame of 1 MiB or more
     StageTimer timer;
     // streaming adapter (ZSTD_decompressStream): whole frames are collected on the host, decoded in batches
     std::vector<u8> dIn, dOut; size_t dOutPos = 0; bool hostage = false;
@@ -655,7 +659,7 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
-        d->frames.release(); d->blocks.release(); d->recs.release(); d->status.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->dict.release(); d->dictInfoDev.release();
+        d->frames.release(); d->blocks.release(); d->recs.release(); d->status.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->dict.release(); d->dictInfoDev.release(); d->origin.release(); d->originList.release();
         d->timer.destroy();
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
@@ -878,11 +882,38 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     d->timer.mark("block_prepass", s);
     const u64 nSeq = (u64)st[kStSeqLo] | ((u64)st[kStSeqHi] << 32);
     if (!d->recs.ensure((size_t)(nSeq + 64) * sizeof(SeqRec))) return ZERR(kErrMemoryAllocation);
+    // Long frames (decode_origin.hip).  The ordered walk of exec_matches moves a frame at about kWalkRate on one wave, all frames at
+    // once; the origin path sweeps the frames it is given at about kSweepRate together.  A frame belongs on the origin path when its
+    // own walk would outlast the sweep of every frame at least as long: the smallest size class 2^(20+k) with
+    // 2^(20+k) / kWalkRate >= bytes(frames >= 2^(20+k)) / kSweepRate, from the per-class sums block_link filed.
+    u64 originMin = 0, originBytes = 0; u32 originCap = 0;
+    if (d->originMode != 1) {
+        constexpr double kWalkRate = 0.15e9, kSweepRate = 20e9;
+        u64 above = 0;
+        u64 sums[12];
+        for (int k = 0; k < 12; ++k) sums[k] = (u64)st[kStBigBins + 2 * k] | ((u64)st[kStBigBins + 2 * k + 1] << 32);
+        for (int k = 11; k >= 0; --k) {
+            above += sums[k];
+            if (!above) continue;
+            const double size = (double)((u64)1 << (20 + k));
+            if (d->originMode == 2 || size / kWalkRate >= (double)above / kSweepRate) { originMin = (u64)1 << (20 + k); originBytes = above; }
+        }
+        if (originMin) {
+            const u64 cap = originBytes / originMin + 1;
+            originCap = (u32)(cap < 65535 ? cap : 65535);       // (a grid dimension; more long frames than that keep the walk)
+            if (!d->origin.ensure((size_t)(originBytes + 64 * (u64)originCap) * sizeof(u32)) || !d->originList.ensure((size_t)originCap * sizeof(u32))) { originMin = 0; (void)hipGetLastError(); }
+        }
+    }
     SeqRec* recs = (SeqRec*)d->recs.p;
     launch_seq_decode(d_src, frames, blocks, nBlocks, recs, status, dictFull, dinfo, s);            d->timer.mark("seq_decode", s);
     launch_block_offsets(frames, blocks, nFrames, dinfo, nUnsized ? 1u : 0u, dstCapacity, status, s);  d->timer.mark("block_offsets", s);
     launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s, d->timer.hook());
     launch_place_literals(d_src, d_dst, (const u8*)d->scratch.p, frames, blocks, nBlocks, recs, status, s);    d->timer.mark("place_literals", s);
+    if (originMin) {
+        launch_origin_select(frames, nFrames, originMin, (u32*)d->originList.p, originCap, originBytes + 64 * (u64)originCap, status, s);
+        launch_origin_exec(frames, blocks, (const u32*)d->originList.p, originCap, originBytes < ((u64)1 << 31) ? originBytes : ((u64)1 << 31), recs, status,
+                           (u32*)d->origin.p, d_dst, dictContent, dictContentSize, s, d->timer.hook());
+    }
     launch_exec_matches(d_src, d_dst, frames, blocks, nFrames, recs, status, dictContent, dictContentSize, s);  d->timer.mark("exec_matches", s);
     if (!read_status(st)) return ZERR(kErrGeneric);
     d->timer.finish();
@@ -1081,6 +1112,7 @@ size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kEr
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->originMode = (int)mode; return 0; }
 size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 3) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* c, unsigned chunks) { if (!c || chunks == 0 || chunks > (1u << 20)) return ZERR(kErrParameterOutOfBound); c->passChunks = chunks; return 0; }
 // bytes: 0 = independent 64 KiB frames; > 0 = cross-chunk history of that many bytes per block (rounded to 4 KiB, at most 48 KiB);
