@@ -28,7 +28,10 @@ namespace zmi {
 // frame (or skippable frame) at pos -> next position.  Returns 0 frame, 1 skippable, or an error code >= 2 (the reference's).
 // `strict`: the parallel walk's view — a frame that names a dictionary is left to the serial walk (which knows the loaded one).
 struct ChainOut { u64 next; u64 content; u64 window; u32 nbBlocks; u32 hdrSize; u32 checksum; u32 unsized; u32 dictID; };
-__device__ inline u32 chain_step(const u8* __restrict__ src, u64 srcSize, u64 pos, ChainOut& o)
+// EMIT: the frame was validated by an earlier walk; this one also writes its blocks' descriptors (block header walks are chains of
+// dependent loads — 0.3 us a block — so a walk that emits must not be a walk of its own behind the one that validates)
+template <bool EMIT>
+__device__ inline u32 chain_step_t(const u8* __restrict__ src, u64 srcSize, u64 pos, ChainOut& o, u32 frameIdx, u32 firstBlock, BlockDesc* __restrict__ blocks)
 {
     o.content = 0; o.nbBlocks = 0; o.hdrSize = 0; o.checksum = 0; o.unsized = 0; o.dictID = 0; o.window = 0; o.next = pos;
     if (srcSize - pos < 5) return kErrSrcSizeWrong;
@@ -50,6 +53,13 @@ __device__ inline u32 chain_step(const u8* __restrict__ src, u64 srcSize, u64 po
         if (type == 3) return kErrCorruption;
         if (type == 1) cSize = 1;
         if (3 + (u64)cSize > srcSize - q) return kErrSrcSizeWrong;
+        if (EMIT) {
+            BlockDesc b = {};
+            b.srcOff = q + 3; b.frame = frameIdx; b.type = (u8)type; b.last = (u8)last;
+            b.bsz = cSize; b.outSize = type == 2 ? 0u : (bh >> 3);
+            b.hufSrc = kNoBlock; b.tblSrc[0] = b.tblSrc[1] = b.tblSrc[2] = kNoBlock;
+            blocks[firstBlock + nb] = b;
+        }
         q += 3 + cSize;
         if (++nb == 0xFFFFFFFFu) return kErrMemoryAllocation;
         if (last) break;
@@ -62,24 +72,18 @@ __device__ inline u32 chain_step(const u8* __restrict__ src, u64 srcSize, u64 po
     return 0;
 }
 
-// the walk's part of every block of the frame at `pos` (already validated by chain_step)
-__device__ inline void emit_frame(const u8* __restrict__ src, u64 pos, const ChainOut& o, u32 frameIdx, u32 firstBlock, u64 dstOff,
-                                  FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks)
+__device__ inline u32 chain_step(const u8* __restrict__ src, u64 srcSize, u64 pos, ChainOut& o) { return chain_step_t<false>(src, srcSize, pos, o, 0, 0, nullptr); }
+
+// the frame at `pos` (validated by an earlier walk) into the lists: ONE walk over its block headers.  -> chain_step's result
+__device__ inline u32 emit_frame(const u8* __restrict__ src, u64 srcSize, u64 pos, ChainOut& o, u32 frameIdx, u32 firstBlock, u64 dstOff,
+                                 FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks)
 {
+    const u32 st = chain_step_t<true>(src, srcSize, pos, o, frameIdx, firstBlock, blocks);
+    if (st) return st;
     FrameDesc f; f.srcOff = pos; f.dstOff = dstOff; f.scratchOff = dstOff; f.srcSize = o.next - pos; f.dstSize = o.content;
     f.firstBlock = firstBlock; f.nbBlocks = o.nbBlocks; f.unsized = o.unsized; f.checksum = o.checksum; f.bad = 0; f.hasSeq = 0; f.viaOrigin = 0; f.pad = 0; f.originOff = 0;
     frames[frameIdx] = f;
-    u64 q = pos + o.hdrSize;
-    for (u32 n = 0; n < o.nbBlocks; ++n) {
-        const u32 bh = readLE24(src + q);
-        const u32 type = (bh >> 1) & 3, sz = bh >> 3;
-        BlockDesc b = {};
-        b.srcOff = q + 3; b.frame = frameIdx; b.type = (u8)type; b.last = (u8)(bh & 1);
-        b.bsz = type == 1 ? 1u : sz; b.outSize = type == 2 ? 0u : sz;
-        b.hufSrc = kNoBlock; b.tblSrc[0] = b.tblSrc[1] = b.tblSrc[2] = kNoBlock;
-        blocks[firstBlock + n] = b;
-        q += 3 + b.bsz;
-    }
+    return 0;
 }
 
 // the exact serial walk (ZSTD_decompressMultiFrame's loop, U/ZstdDecompress.cs:1216-1315), one lane.  emit = 0: count frames and
@@ -91,12 +95,12 @@ __global__ void frame_walk_serial_kernel(const u8* __restrict__ src, u64 srcSize
     u64 pos = 0, dstOff = 0; u32 n = 0, err = 0, nUnsized = 0; u64 nBlocks = 0;
     while (srcSize - pos >= 5) {            // ZSTD_decompressMultiFrame loop condition (U/ZstdDecompress.cs:1228)
         ChainOut o;
-        const u32 st = chain_step(src, srcSize, pos, o);
+        // (emit: the same input has been through the counting pass, which stopped at the first error and sized the lists)
+        const u32 st = emit ? emit_frame(src, srcSize, pos, o, n, (u32)nBlocks, dstOff, frames, blocks) : chain_step(src, srcSize, pos, o);
         if (st == 1) { pos = o.next; continue; }
         if (st) { err = (st == kErrPrefixUnknown && n > 0) ? (u32)kErrSrcSizeWrong : st; break; }
         if (o.dictID && o.dictID != dictID) { err = kErrDictionaryWrong; break; }       // U/ZstdDecompress.cs:1404-1412 (dictID 0 = none loaded)
         if (n >= maxFrames || nBlocks + o.nbBlocks > 0xFFFFFFF0ull) { err = kErrMemoryAllocation; break; }
-        if (emit) emit_frame(src, pos, o, n, (u32)nBlocks, dstOff, frames, blocks);
         n++; nUnsized += o.unsized; nBlocks += o.nbBlocks;
         dstOff += o.content; pos = o.next;
     }
@@ -213,9 +217,9 @@ __global__ __launch_bounds__(256) void walk_emit_kernel(const u8* __restrict__ s
     u64 pos = g.entry, dstOff = dstBase[s]; u32 idx = frameBase[s], blk = blockBase[s];
     while (pos < g.exit) {
         ChainOut o;
-        const u32 st = chain_step(src, srcSize, pos, o);
+        const u32 st = emit_frame(src, srcSize, pos, o, idx, blk, dstOff, frames, blocks);
         if (st >= 2) return;                                   // cannot happen: the chain was validated by walk_segments
-        if (st == 0) { emit_frame(src, pos, o, idx, blk, dstOff, frames, blocks); idx++; blk += o.nbBlocks; dstOff += o.content; }
+        if (st == 0) { idx++; blk += o.nbBlocks; dstOff += o.content; }
         pos = o.next;
     }
 }
@@ -304,47 +308,79 @@ __global__ __launch_bounds__(256) void block_parse_kernel(const u8* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
-// block_link: table provenance inside a frame, literal offsets; one lane per frame
+// block_link: table provenance inside a frame, literal offsets; one wave per frame, 64 blocks at a time
 // ------------------------------------------------------------------------------------------------
+// "the latest earlier block that ..." over the 64 blocks of a batch: the highest lane below mine in `mask`, else what earlier batches left
+__device__ __forceinline__ u32 latest_before(u64 mask, u32 firstOfBatch, u32 carried, u32 lane)
+{
+    const u64 prior = mask & lanemask_lt();
+    return prior ? firstOfBatch + (63u - (u32)__builtin_clzll(prior)) : carried;
+}
 __global__ __launch_bounds__(64) void block_link_kernel(FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks, u32 nFrames, u32 haveDict,
                                                         u32* __restrict__ status)
 {
-    const u32 f = blockIdx.x * 64 + threadIdx.x;
+    const u32 f = blockIdx.x, lane = threadIdx.x;
     if (f >= nFrames) return;
     FrameDesc& F = frames[f];
+    const u32 first = uniform(F.firstBlock), nb = uniform(F.nbBlocks);
+    const u64 dstSize = F.dstSize;
     // a formatted dictionary: every frame starts from its Huffman table and its three FSE tables (ZSTD_decompressBegin_usingDict,
     // U/ZstdDecompress.cs:1956-1990); without one nothing is defined before the frame's first block defines it
     u32 lastHuf = haveDict ? kDictBlock : kNoBlock;
-    u32 lastTbl[3] = { lastHuf, lastHuf, lastHuf };
+    u32 lastTbl0 = lastHuf, lastTbl1 = lastHuf, lastTbl2 = lastHuf;
     u64 litAcc = 0; u32 hasSeq = 0;
-    for (u32 k = 0; k < F.nbBlocks; ++k) {
-        const u32 bi = F.firstBlock + k;
-        BlockDesc& B = blocks[bi];
-        if (B.type != 2 || B.err) continue;
+    for (u32 k0 = 0; k0 < nb; k0 += 64) {
+        const u32 bi = first + k0 + lane;
+        const bool have = k0 + lane < nb;
+        u32 litType = 0, litSize = 0, nbSeq = 0, modes = 0; bool live = false;
+        if (have) {
+            const BlockDesc& B = blocks[bi];
+            live = B.type == 2 && !B.err;
+            if (live) { litType = B.litType; litSize = B.litSize; nbSeq = B.nbSeq; modes = B.modes; }
+        }
         u32 err = 0;
-        if (B.litType == 2) { lastHuf = bi; B.hufSrc = bi; }
-        else if (B.litType == 3) { B.hufSrc = lastHuf; if (lastHuf == kNoBlock) err = kErrDictionaryCorrupted; }     // U/ZstdDecompressBlock.cs:197-207
-        if (B.litType >= 2) {
-            // (the frame's literal scratch is dstSize long: a block that does not fit takes none of it, so the bound holds for the
-            //  blocks behind it whatever later kernels do with the frame)
-            if (B.litSize > F.dstSize - litAcc) { err = err ? err : (u32)kErrCorruption; B.litRel = 0; }
-            else { B.litRel = litAcc; litAcc += B.litSize; }
-        }
-        if (B.nbSeq) {
-            hasSeq = 1;
+        // the Huffman table of a treeless literals section is the latest one defined in front of it (U/ZstdDecompressBlock.cs:197-207)
+        const u64 defHuf = ballot(live && litType == 2);
+        u32 hufSrc = kNoBlock;
+        if (live && litType == 2) hufSrc = bi;
+        else if (live && litType == 3) { hufSrc = latest_before(defHuf, first + k0, lastHuf, lane); if (hufSrc == kNoBlock) err = kErrDictionaryCorrupted; }
+        if (defHuf) lastHuf = first + k0 + (63u - (u32)__builtin_clzll(defHuf));
+        // regenerated literals of Huffman-coded sections, one after the other in the frame's scratch (dstSize long: a block that does
+        // not fit takes none of it and is an error, so the bound holds for every block whatever later kernels do with the frame)
+        const bool coded = live && litType >= 2;
+        const u64 mine = coded ? litSize : 0u;
+        u64 incl = mine;
 #pragma unroll
-            for (u32 t = 0; t < 3; ++t) {
-                const u32 mode = (B.modes >> (6 - 2 * t)) & 3;
-                if (mode == 3) { B.tblSrc[t] = lastTbl[t]; if (lastTbl[t] == kNoBlock) err = err ? err : (u32)kErrCorruption; }   // :1780-1786
-                else { B.tblSrc[t] = bi; lastTbl[t] = bi; }
-            }
+        for (int d = 1; d < 64; d <<= 1) { const u64 t = __shfl_up(incl, d); if ((int)lane >= d) incl += t; }
+        u64 litRel = litAcc + incl - mine;
+        if (coded && litRel + mine > dstSize) { err = err ? err : (u32)kErrCorruption; litRel = 0; }
+        litAcc += __shfl(incl, 63);
+        // repeat-mode FSE tables: the latest table of that kind defined in front of the block (:1780-1786)
+        const bool seqs = live && nbSeq != 0;
+        if (ballot(seqs)) hasSeq = 1;
+        u32 src3[3];
+#pragma unroll
+        for (u32 t = 0; t < 3; ++t) {
+            const u32 mode = (modes >> (6 - 2 * t)) & 3;
+            const u64 def = ballot(seqs && mode != 3);
+            u32& last = t == 0 ? lastTbl0 : t == 1 ? lastTbl1 : lastTbl2;
+            src3[t] = bi;
+            if (seqs && mode == 3) { src3[t] = latest_before(def, first + k0, last, lane); if (src3[t] == kNoBlock) err = err ? err : (u32)kErrCorruption; }
+            if (def) last = first + k0 + (63u - (u32)__builtin_clzll(def));
         }
-        if (err) { B.err = err; report_error(status, bi, B.litType >= 2 && (err == kErrDictionaryCorrupted || B.litSize > F.dstSize) ? kStageLiterals : kStageSequences, err); }
+        if (live) {
+            BlockDesc& B = blocks[bi];
+            if (litType >= 2) { B.hufSrc = hufSrc; B.litRel = litRel; }
+            if (seqs) { B.tblSrc[0] = src3[0]; B.tblSrc[1] = src3[1]; B.tblSrc[2] = src3[2]; }
+            if (err) { B.err = err; report_error(status, bi, litType >= 2 && (err == kErrDictionaryCorrupted || litSize > dstSize) ? kStageLiterals : kStageSequences, err); }
+        }
     }
-    F.hasSeq = hasSeq;
-    // long frames by size class: what the host decides the origin path from (decode_origin.hip); a frame without a content size counts with its bound
-    if (hasSeq && F.dstSize >= (1u << 20) && F.dstSize < (1ull << 31))
-        atomicAdd(reinterpret_cast<unsigned long long*>(status + kStBigBins) + highbit32((u32)(F.dstSize >> 20)), (unsigned long long)F.dstSize);
+    if (lane == 0) {
+        F.hasSeq = hasSeq;
+        // long frames by size class: what the host decides the origin path from (decode_origin.hip); a frame without a content size counts with its bound
+        if (hasSeq && dstSize >= (1u << 20) && dstSize < (1ull << 30))
+            atomicAdd(reinterpret_cast<unsigned long long*>(status + kStBigBins) + highbit32((u32)(dstSize >> 20)), (unsigned long long)dstSize);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -376,7 +412,7 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(BlockDesc* __restrict__ 
 void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32* status, hipStream_t stream)
 {
     hipLaunchKernelGGL(block_parse_kernel, dim3((nBlocks + 255) / 256), dim3(256), 0, stream, src, blocks, nBlocks, status);
-    hipLaunchKernelGGL(block_link_kernel, dim3((nFrames + 63) / 64), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, status);
+    hipLaunchKernelGGL(block_link_kernel, dim3(nFrames), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, status);
     hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, stream, blocks, nBlocks, status);
 }
 

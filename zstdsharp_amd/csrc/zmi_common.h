@@ -146,7 +146,7 @@ enum : u32 { kStFrames = 0, kStErr = 1, kStTotalLo = 2, kStTotalHi = 3, kStUsabl
              kStOriginFrames = 14,      // frames the origin path took (origin_select_kernel)
              kStOriginLo = 16, kStOriginHi = 17,        // entries of the origin array handed out so far (u64)
              kStOriginChanged = 18,     // .. 18 + kOriginRounds: round r of the pointer jumping changed something
-             kStBigBins = 56,           // 12 x u64: content bytes of the frames with sequences by size class, bin k = [2^(20+k), 2^(21+k)) (bin 11: up to 2^31)
+             kStBigBins = 56,           // 12 x u64: content bytes of the frames with sequences by size class, bin k = [2^(20+k), 2^(21+k)), below 2^30
              kStWords = 80 };
 constexpr u32 kOriginRounds = 36;
 

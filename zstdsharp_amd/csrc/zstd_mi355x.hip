@@ -48,8 +48,10 @@ void launch_place_literals(const u8* src, u8* out, const u8* scratch, const Fram
 void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
                          const u8* dict, u32 dictSize, hipStream_t stream);
 void launch_origin_select(FrameDesc* frames, u32 nFrames, u64 minBytes, u32* list, u32 listCap, u64 originCap, u32* status, hipStream_t stream);
-void launch_origin_exec(const FrameDesc* frames, const BlockDesc* blocks, const u32* list, u32 listCap, u64 maxFrameBytes, const SeqRec* recs, u32* status,
-                        u32* origin, u8* out, const u8* dict, u32 dictSize, hipStream_t stream, StageHook hook);
+void launch_origin_init(const FrameDesc* frames, const BlockDesc* blocks, const u32* list, u32 listCap, u64 maxFrameBytes, const SeqRec* recs, u32* status,
+                        u32* origin, u32 dictSize, hipStream_t stream);
+void launch_origin_jump(const FrameDesc* frames, const u32* list, u32 listCap, u64 maxFrameBytes, u32* status, u32* origin, u32* done, u32 r0, u32 r1, hipStream_t stream);
+void launch_origin_gather(const FrameDesc* frames, const u32* list, u32 listCap, u64 maxFrameBytes, const u32* status, const u32* origin, u8* out, const u8* dict, hipStream_t stream);
 }
 
 using namespace zmi;
@@ -886,7 +888,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     // once; the origin path sweeps the frames it is given at about kSweepRate together.  A frame belongs on the origin path when its
     // own walk would outlast the sweep of every frame at least as long: the smallest size class 2^(20+k) with
     // 2^(20+k) / kWalkRate >= bytes(frames >= 2^(20+k)) / kSweepRate, from the per-class sums block_link filed.
-    u64 originMin = 0, originBytes = 0; u32 originCap = 0;
+    u64 originMin = 0, originBytes = 0, originLongest = 0; u32 originCap = 0;
     if (d->originMode != 1) {
         constexpr double kWalkRate = 0.15e9, kSweepRate = 20e9;
         u64 above = 0;
@@ -899,9 +901,14 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
             if (d->originMode == 2 || size / kWalkRate >= (double)above / kSweepRate) { originMin = (u64)1 << (20 + k); originBytes = above; }
         }
         if (originMin) {
-            const u64 cap = originBytes / originMin + 1;
+            // how many frames that can be (a frame of class k holds at least 2^(20+k) bytes) and how long the longest (below 2^(21+k))
+            u64 cap = 0;
+            for (int k = 0; k < 12; ++k) if (((u64)1 << (20 + k)) >= originMin && sums[k]) { cap += sums[k] >> (20 + k); originLongest = (u64)1 << (21 + k); }
+            if (originLongest > originBytes) originLongest = originBytes;
             originCap = (u32)(cap < 65535 ? cap : 65535);       // (a grid dimension; more long frames than that keep the walk)
-            if (!d->origin.ensure((size_t)(originBytes + 64 * (u64)originCap) * sizeof(u32)) || !d->originList.ensure((size_t)originCap * sizeof(u32))) { originMin = 0; (void)hipGetLastError(); }
+            // (+ one word per 1024 origins: origin_jump_kernel's finished regions)
+            if (!d->origin.ensure((size_t)(originBytes + 1024 * (u64)originCap) * sizeof(u32) + (size_t)((originBytes + 1024 * (u64)originCap) / 1024 + 64) * sizeof(u32)) ||
+                !d->originList.ensure((size_t)originCap * sizeof(u32))) { originMin = 0; (void)hipGetLastError(); }
         }
     }
     SeqRec* recs = (SeqRec*)d->recs.p;
@@ -910,9 +917,22 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s, d->timer.hook());
     launch_place_literals(d_src, d_dst, (const u8*)d->scratch.p, frames, blocks, nBlocks, recs, status, s);    d->timer.mark("place_literals", s);
     if (originMin) {
-        launch_origin_select(frames, nFrames, originMin, (u32*)d->originList.p, originCap, originBytes + 64 * (u64)originCap, status, s);
-        launch_origin_exec(frames, blocks, (const u32*)d->originList.p, originCap, originBytes < ((u64)1 << 31) ? originBytes : ((u64)1 << 31), recs, status,
-                           (u32*)d->origin.p, d_dst, dictContent, dictContentSize, s, d->timer.hook());
+        const u64 entries = originBytes + 1024 * (u64)originCap, longest = originLongest;
+        u32* const origin = (u32*)d->origin.p; const u32* const list = (const u32*)d->originList.p;
+        launch_origin_select(frames, nFrames, originMin, (u32*)d->originList.p, originCap, entries, status, s);
+        launch_origin_init(frames, blocks, list, originCap, longest, recs, status, origin, dictContent ? dictContentSize : 0u, s);    d->timer.mark("origin_init", s);
+        // The rounds in groups of six, the host looking at the last one's verdict in between: ordinary data settles in about ten
+        // rounds, and a round that only finds out that nothing is left still costs its launch (the kernels check the flag too).
+        for (u32 r = 0; r < kOriginRounds; r += 6) {
+            launch_origin_jump(frames, list, originCap, longest, status, origin, origin + entries, r, r + 6, s);
+            u32 open = 0;
+            const u32 lastRound = (r + 6 < kOriginRounds ? r + 6 : kOriginRounds) - 1;
+            if (hipMemcpyAsync(&open, status + kStOriginChanged + lastRound, sizeof(u32), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+            if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+            if (!open) break;
+        }
+        d->timer.mark("origin_jump", s);
+        launch_origin_gather(frames, list, originCap, longest, status, origin, d_dst, dictContent, s);    d->timer.mark("origin_gather", s);
     }
     launch_exec_matches(d_src, d_dst, frames, blocks, nFrames, recs, status, dictContent, dictContentSize, s);  d->timer.mark("exec_matches", s);
     if (!read_status(st)) return ZERR(kErrGeneric);
