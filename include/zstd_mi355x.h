@@ -147,6 +147,9 @@ size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* dctx, unsigned mode);
  * (default: a frame whose ordered one-wave walk would take longer than a parallel sweep of all such frames is resolved by origin
  * pointers — decode_origin.hip —, the others are walked), 1 = always the walk, 2 = origin pointers for every frame of 1 MiB or more */
 size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* dctx, unsigned mode);
+/* the literal decoder beside the sequence decoder on a second stream (they need nothing of each other): 0 = when a call has few
+ * blocks (default: neither kernel fills the chip then), 1 = never, 2 = always */
+size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* dctx, unsigned mode);
 
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
 size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);

@@ -36,7 +36,7 @@ __device__ __forceinline__ bool lit_job(LitJob& J, u32 bi, const BlockDesc* __re
     else if (B.hufSrc == kDictBlock) { J.tsrc = dictFull + di->hufOff; J.tlen = di->hufSize; J.tErr = kErrDictionaryCorrupted; }
     else { const BlockDesc& S = blocks[B.hufSrc]; J.tsrc = src + S.srcOff + S.lhSize; J.tlen = S.litCSize; }
     // a block without sequences regenerates exactly its literals: they are decoded in place
-    J.dst = B.nbSeq == 0 ? out + F.dstOff + B.dstRel : scratch + F.scratchOff + B.litRel + (u64)B.frame * kLitSkew;
+    J.dst = B.litInPlace ? out + F.dstOff + B.dstRel : scratch + F.scratchOff + B.litRel + (u64)B.frame * kLitSkew;
     return true;
 }
 

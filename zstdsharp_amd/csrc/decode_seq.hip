@@ -440,7 +440,7 @@ __global__ __launch_bounds__(64) void place_literals_kernel(const u8* __restrict
         return;
     }
     const u32 litType = uniform((u32)B.litType), litSize = uniform(B.litSize), nbSeq = uniform(B.nbSeq);
-    if (nbSeq == 0 && litType >= 2) return;                     // decoded in place by the literal decoder
+    if (uniform(B.litInPlace)) return;                          // decoded in place by the literal decoder
     const u8* __restrict__ lit = nullptr; u32 rleByte = 0; const bool litIsRle = litType == 1;
     if (litType >= 2) lit = scratch + F.scratchOff + B.litRel + (u64)B.frame * kLitSkew;
     else if (litType == 0) lit = src + B.srcOff + B.lhSize;

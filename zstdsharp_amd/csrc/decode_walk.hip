@@ -317,7 +317,7 @@ __device__ __forceinline__ u32 latest_before(u64 mask, u32 firstOfBatch, u32 car
     return prior ? firstOfBatch + (63u - (u32)__builtin_clzll(prior)) : carried;
 }
 __global__ __launch_bounds__(64) void block_link_kernel(FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks, u32 nFrames, u32 haveDict,
-                                                        u32* __restrict__ status)
+                                                        u32 earlyLiterals, u32* __restrict__ status)
 {
     const u32 f = blockIdx.x, lane = threadIdx.x;
     if (f >= nFrames) return;
@@ -370,13 +370,19 @@ __global__ __launch_bounds__(64) void block_link_kernel(FrameDesc* __restrict__ 
         }
         if (live) {
             BlockDesc& B = blocks[bi];
-            if (litType >= 2) { B.hufSrc = hufSrc; B.litRel = litRel; }
+            if (litType >= 2) {
+                B.hufSrc = hufSrc; B.litRel = litRel;
+                // earlyLiterals: the literal decoder runs beside seq_decode, i.e. before block_offsets: only where the output offset is
+                // known by now — the first block of a frame with a content size — can it write the output itself
+                B.litInPlace = (nbSeq == 0 && (!earlyLiterals || (k0 + lane == 0 && !F.unsized))) ? 1u : 0u;
+            }
             if (seqs) { B.tblSrc[0] = src3[0]; B.tblSrc[1] = src3[1]; B.tblSrc[2] = src3[2]; }
             if (err) { B.err = err; report_error(status, bi, litType >= 2 && (err == kErrDictionaryCorrupted || litSize > dstSize) ? kStageLiterals : kStageSequences, err); }
         }
     }
     if (lane == 0) {
         F.hasSeq = hasSeq;
+        if (litAcc) atomicAdd(reinterpret_cast<unsigned long long*>(status + kStLitLo), (unsigned long long)litAcc);
         // long frames by size class: what the host decides the origin path from (decode_origin.hip); a frame without a content size counts with its bound
         if (hasSeq && dstSize >= (1u << 20) && dstSize < (1ull << 30))
             atomicAdd(reinterpret_cast<unsigned long long*>(status + kStBigBins) + highbit32((u32)(dstSize >> 20)), (unsigned long long)dstSize);
@@ -409,10 +415,10 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(BlockDesc* __restrict__ 
     if (tid == 0) { status[kStSeqLo] = (u32)carry; status[kStSeqHi] = (u32)(carry >> 32); }
 }
 
-void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32* status, hipStream_t stream)
+void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32 earlyLiterals, u32* status, hipStream_t stream)
 {
     hipLaunchKernelGGL(block_parse_kernel, dim3((nBlocks + 255) / 256), dim3(256), 0, stream, src, blocks, nBlocks, status);
-    hipLaunchKernelGGL(block_link_kernel, dim3(nFrames), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, status);
+    hipLaunchKernelGGL(block_link_kernel, dim3(nFrames), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, earlyLiterals, status);
     hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, stream, blocks, nBlocks, status);
 }
 

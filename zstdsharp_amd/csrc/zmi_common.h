@@ -129,6 +129,8 @@ struct BlockDesc {
     u32 repKind[3], repVal[3];
     u32 repIn[3];       // the three repcodes at the block's start (block_offsets)
     u32 err;            // first error found in this block (0 = none)
+    u32 litInPlace;     // 1 = no sequences: the literal decoder writes the block's output itself (block_link decides; when the literal
+                        // decoder runs beside seq_decode only a sized frame's first block can — the others' offsets are not known yet)
 };
 
 // One decoded sequence (U/ZstdDecompressBlock.cs:2360-2484) as seq_decode leaves it for the executors, packed into 8 bytes:
@@ -146,6 +148,7 @@ enum : u32 { kStFrames = 0, kStErr = 1, kStTotalLo = 2, kStTotalHi = 3, kStUsabl
              kStOriginFrames = 14,      // frames the origin path took (origin_select_kernel)
              kStOriginLo = 16, kStOriginHi = 17,        // entries of the origin array handed out so far (u64)
              kStOriginChanged = 18,     // .. 18 + kOriginRounds: round r of the pointer jumping changed something
+             kStLitLo = 54, kStLitHi = 55,              // regenerated bytes of all Huffman-coded literals sections (u64; block_link)
              kStBigBins = 56,           // 12 x u64: content bytes of the frames with sequences by size class, bin k = [2^(20+k), 2^(21+k)), below 2^30
              kStWords = 80 };
 constexpr u32 kOriginRounds = 36;

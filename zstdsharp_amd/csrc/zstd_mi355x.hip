@@ -37,7 +37,7 @@ void launch_frame_walk_emit(const u8* src, u64 srcSize, FrameDesc* frames, Block
 void launch_frame_walk_serial(const u8* src, u64 srcSize, FrameDesc* frames, BlockDesc* blocks, u32 maxFrames, u32* status, u32 dictID, u32 emit,
                               hipStream_t stream);
 void launch_dict_parse(const u8* dict, u32 dictSize, DictInfo* out, hipStream_t stream);
-void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32* status, hipStream_t stream);
+void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32 earlyLiterals, u32* status, hipStream_t stream);
 void launch_seq_decode(const u8* src, const FrameDesc* frames, BlockDesc* blocks, u32 nBlocks, SeqRec* recs, u32* status,
                        const u8* dictFull, const DictInfo* di, hipStream_t stream);
 void launch_block_offsets(FrameDesc* frames, BlockDesc* blocks, u32 nFrames, const DictInfo* di, u32 rescan, u64 dstCapacity, u32* status, hipStream_t stream);
@@ -173,6 +173,8 @@ struct ZSTD_DCtx_s {
     int windowLogMax = 27;
     int device = 0; bool deviceOk = false;
     hipStream_t ownStream = nullptr, stream = nullptr;
+    hipStream_t aux = nullptr; hipEvent_t auxDone = nullptr;     // the literal decoder beside seq_decode (decompress_device)
+    int overlapMode = 0;        // ZSTDMI_DCtx_setOverlap: 0 = by block count, 1 = never, 2 = always
     DevBuf frames, blocks, recs, status, scratch, walkWs, slowFlags, stageSrc, stageDst, origin, originList;
     int originMode = 0;         // ZSTDMI_DCtx_setLongFrames: 0 = by cost (see decompress_device), 1 = never, 2 = every frame of 1 MiB or more
     StageTimer timer;
@@ -207,6 +209,8 @@ static size_t dctx_bind(ZSTD_DCtx* d)
         if (device_count() <= d->device) return ZERR(kErrInitMissing);
         if (hipSetDevice(d->device) != hipSuccess) return ZERR(kErrInitMissing);
         if (!d->ownStream && hipStreamCreateWithFlags(&d->ownStream, hipStreamNonBlocking) != hipSuccess) return ZERR(kErrMemoryAllocation);
+        if (!d->aux && hipStreamCreateWithFlags(&d->aux, hipStreamNonBlocking) != hipSuccess) return ZERR(kErrMemoryAllocation);
+        if (!d->auxDone && hipEventCreateWithFlags(&d->auxDone, hipEventDisableTiming) != hipSuccess) return ZERR(kErrMemoryAllocation);
         if (!d->stream) d->stream = d->ownStream;
         d->deviceOk = true;
     } else if (hipSetDevice(d->device) != hipSuccess) return ZERR(kErrInitMissing);
@@ -663,6 +667,8 @@ size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
         d->frames.release(); d->blocks.release(); d->recs.release(); d->status.release(); d->scratch.release(); d->walkWs.release(); d->slowFlags.release(); d->stageSrc.release(); d->stageDst.release(); d->dict.release(); d->dictInfoDev.release(); d->origin.release(); d->originList.release();
         d->timer.destroy();
+        if (d->aux) { (void)hipStreamSynchronize(d->aux); (void)hipStreamDestroy(d->aux); }
+        if (d->auxDone) (void)hipEventDestroy(d->auxDone);
         if (d->ownStream) (void)hipStreamDestroy(d->ownStream);
     }
     delete d;
@@ -879,7 +885,13 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     if (serialWalk) launch_frame_walk_serial(d_src, srcSize, frames, blocks, maxFrames, status, dictID, 1, s);
     else            launch_frame_walk_emit(d_src, srcSize, frames, blocks, (u8*)d->walkWs.p, s);
     d->timer.mark("frame_walk", s);
-    launch_block_prepass(d_src, frames, blocks, nFrames, nBlocks, fmt ? 1u : 0u, status, s);
+    // The literal decoder and seq_decode need nothing of each other (a block's Huffman streams and its FSE chains).  With few
+    // blocks neither fills the chip — both are serial chains per block — so below kOverlapBlocks the literal decoder may run beside
+    // seq_decode on a stream of its own (`early`: block_link then lets it write only the outputs whose place is known by now).
+    // Whether it does is decided once the pre-pass has counted both kinds of work (below).
+    constexpr u32 kOverlapBlocks = 24576;
+    const bool early = d->overlapMode == 2 || (d->overlapMode == 0 && nBlocks <= kOverlapBlocks);
+    launch_block_prepass(d_src, frames, blocks, nFrames, nBlocks, fmt ? 1u : 0u, early ? 1u : 0u, status, s);
     if (!read_status(st)) return ZERR(kErrGeneric);
     d->timer.mark("block_prepass", s);
     const u64 nSeq = (u64)st[kStSeqLo] | ((u64)st[kStSeqHi] << 32);
@@ -912,9 +924,22 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
         }
     }
     SeqRec* recs = (SeqRec*)d->recs.p;
+    struct AuxGuard { hipStream_t a; bool on; ~AuxGuard() { if (on) (void)hipStreamSynchronize(a); } } auxGuard{ d->aux, false };   // nothing of this call outlives it
+    // Beside each other only when both are substantial: a Huffman symbol costs its chain about 20 ns per literal byte (four streams),
+    // a sequence about 270 ns — text (two literal bytes per sequence) has nothing to hide behind seq_decode and only loses LDS
+    // bandwidth to the company (measured: 1 GiB of 1 MiB level-5 frames, mixed corpus 14.7 -> 13.4 ms, text 15.5 -> 15.7 ms), and
+    // input without sequences (Zipf bytes) has no seq_decode to hide behind.
+    const u64 litBytes = (u64)st[kStLitLo] | ((u64)st[kStLitHi] << 32);
+    const bool beside = early && nSeq && (d->overlapMode == 2 || (litBytes >= 4 * nSeq && nSeq >= 64 * (u64)nBlocks));
+    if (beside) {               // (the host has just waited for the pre-pass: everything the literal decoder reads is there)
+        launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, d->aux, StageHook());
+        if (hipEventRecord(d->auxDone, d->aux) != hipSuccess) return ZERR(kErrGeneric);
+        auxGuard.on = true;
+    }
     launch_seq_decode(d_src, frames, blocks, nBlocks, recs, status, dictFull, dinfo, s);            d->timer.mark("seq_decode", s);
     launch_block_offsets(frames, blocks, nFrames, dinfo, nUnsized ? 1u : 0u, dstCapacity, status, s);  d->timer.mark("block_offsets", s);
-    launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s, d->timer.hook());
+    if (auxGuard.on) { if (hipStreamWaitEvent(s, d->auxDone, 0) != hipSuccess) return ZERR(kErrGeneric); d->timer.mark("decode_literals", s); }     // (what of it seq_decode did not cover)
+    else launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, s, d->timer.hook());
     launch_place_literals(d_src, d_dst, (const u8*)d->scratch.p, frames, blocks, nBlocks, recs, status, s);    d->timer.mark("place_literals", s);
     if (originMin) {
         const u64 entries = originBytes + 1024 * (u64)originCap, longest = originLongest;
@@ -1132,6 +1157,7 @@ size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kEr
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->overlapMode = (int)mode; return 0; }
 size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->originMode = (int)mode; return 0; }
 size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 3) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
 size_t ZSTDMI_CCtx_setPassChunks(ZSTD_CCtx* c, unsigned chunks) { if (!c || chunks == 0 || chunks > (1u << 20)) return ZERR(kErrParameterOutOfBound); c->passChunks = chunks; return 0; }
