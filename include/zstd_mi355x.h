@@ -117,6 +117,14 @@ size_t ZSTD_DStreamOutSize(void);
 int    ZSTDMI_deviceCount(void);                       /* number of visible MI355X devices; 0 => every call fails loudly */
 size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* cctx, int device);
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* dctx, int device);
+/* Several GPUs behind one context (north_star: "chunks partition naturally across the 8 GPUs of one node"): one device worker per
+ * entry of `devices` (an ordinal may be listed more than once).  ZSTD_compress2 / ZSTD_compressCCtx / ZSTD_decompressDCtx and the
+ * device-pointer calls then deal the call's frames to the workers in contiguous shares — each stages, compresses or decodes its share on
+ * its own device and stream — and copy the results one behind the other into the caller's buffer.  The bytes written do not depend on
+ * the number of workers.  n <= 1 returns to a single device.  (The torch.distributed path of bench.py — one process per GPU, RCCL
+ * all-gather-v of the shards — is the other way to use a node; this one needs no process group.) */
+size_t ZSTDMI_CCtx_setDevices(ZSTD_CCtx* cctx, const int* devices, int n);
+size_t ZSTDMI_DCtx_setDevices(ZSTD_DCtx* dctx, const int* devices, int n);
 /* run on a caller-owned HIP stream (e.g. torch's current stream); NULL restores the context's own stream */
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* cctx, void* hipStream);
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* dctx, void* hipStream);

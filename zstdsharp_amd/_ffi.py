@@ -53,6 +53,8 @@ SIGNATURES = {
     "ZSTDMI_deviceCount": (c_int, []),
     "ZSTDMI_CCtx_setDevice": (c_size_t, [c_void_p, c_int]),
     "ZSTDMI_DCtx_setDevice": (c_size_t, [c_void_p, c_int]),
+    "ZSTDMI_CCtx_setDevices": (c_size_t, [c_void_p, ctypes.POINTER(c_int), c_int]),
+    "ZSTDMI_DCtx_setDevices": (c_size_t, [c_void_p, ctypes.POINTER(c_int), c_int]),
     "ZSTDMI_CCtx_setStream": (c_size_t, [c_void_p, c_void_p]),
     "ZSTDMI_DCtx_setStream": (c_size_t, [c_void_p, c_void_p]),
     "ZSTDMI_CCtx_setPassChunks": (c_size_t, [c_void_p, c_uint]),

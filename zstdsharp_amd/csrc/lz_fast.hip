@@ -1566,7 +1566,8 @@ size_t lz_fast_lds_bytes() { return sizeof(LzLds); }
 // independent Zipf(1.1) strings has probability 2e-10; the 6-byte hash with its tag lets a hundredth of a pair per tile through).
 // (One workgroup per tile, reads 64 KiB: an eighth of the input at eight tiles per 4 MiB.)
 constexpr u32 kProbeBack = 60u << 10;
-__global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ src, u64 srcSize, u64 groupBytes, u32 tilesPerGroup, u32* __restrict__ out)
+// front: bytes of the input readable in front of src (a device worker's share of a call: the window in front of its first tiles)
+__global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ src, u64 srcSize, u64 front, u64 groupBytes, u32 tilesPerGroup, u32* __restrict__ out)
 {
     __shared__ u32 firstSeen[1u << kHashLog];
     const u32 tid = threadIdx.x;
@@ -1595,7 +1596,7 @@ __global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ sr
         }
     }
     // (B) the window in front of the tile against the tile's table
-    const u32 back = avail < 16 ? 0u : off < kProbeBack ? (u32)off : kProbeBack;       // (the last read of the window reaches 7 bytes into the tile)
+    const u32 back = avail < 16 ? 0u : off + front < kProbeBack ? (u32)(off + front) : kProbeBack;       // (the last read of the window reaches 7 bytes into the tile)
     const u8* __restrict__ win = in - back;
     for (u32 p = tid; p < back; p += 256) {
         const u64 w = readLE64(win + p);
@@ -1607,10 +1608,10 @@ __global__ __launch_bounds__(256) void lz_probe_kernel(const u8* __restrict__ sr
     if (lane_id() == 0 && cnt) atomicAdd(&out[g], cnt);
 }
 
-void launch_lz_probe(const u8* src, u64 srcSize, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream)
+void launch_lz_probe(const u8* src, u64 srcSize, u64 front, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream)
 {
     (void)hipMemsetAsync(out, 0, (size_t)nGroups * sizeof(u32), stream);
-    hipLaunchKernelGGL(lz_probe_kernel, dim3(nGroups * tilesPerGroup), dim3(256), 0, stream, src, srcSize, groupBytes, tilesPerGroup, out);
+    hipLaunchKernelGGL(lz_probe_kernel, dim3(nGroups * tilesPerGroup), dim3(256), 0, stream, src, srcSize, front, groupBytes, tilesPerGroup, out);
 }
 
 #ifdef ZMI_LZ_STAMPS

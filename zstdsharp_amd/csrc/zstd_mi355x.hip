@@ -10,6 +10,7 @@
 #include <vector>
 #include <cstring>
 #include <mutex>
+#include <thread>
 #include <new>
 #include "zmi_common.h"
 #include "zmi_cparams.h"
@@ -19,7 +20,7 @@ namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
                u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook);
-void launch_lz_probe(const u8* src, u64 srcSize, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream);
+void launch_lz_probe(const u8* src, u64 srcSize, u64 front, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream, StageHook hook);
 void launch_huf_encode(const u8* lits, const ChunkMeta* meta, const HufTable* tables, u8* slots, u8* dst, const u64* offsets, u64 dstCapacity,
@@ -154,6 +155,10 @@ struct ZSTD_CCtx_s {
     // tables are not used (every block carries its own), which any decoder holding the dictionary accepts.
     std::vector<u8> dictHost, dictFull; DevBuf dict, dictFullDev, dictInfoDev; bool dictDirty = false, dictFormatted = false;
     DictInfo info = {};
+    u64 dictGen = 0;            // bumped by every ZSTD_CCtx_loadDictionary: device workers copy the dictionary when theirs is older
+    // ZSTDMI_CCtx_setDevices: one worker context per listed device (its own stream and workspaces there); a call's frames are
+    // dealt to them in contiguous shares (compress_multi).  Empty = the context's own device only.
+    std::vector<ZSTD_CCtx_s*> workers;
 };
 // History per chunk lives in LDS beside the chunk: up to 32 KiB of dictionary in front of 32 KiB chunks, or up to 60 KiB when
 // the whole input fits behind it in one chunk (small records, the usual dictionary case).
@@ -185,6 +190,8 @@ struct ZSTD_DCtx_s {
     // history.  Formatted (magic 0xEC30A437): dict_parse_kernel validates the header and fills `info`; the history is the content.
     std::vector<u8> dictHost; DevBuf dict, dictInfoDev; bool dictDirty = false, dictFormatted = false;
     DictInfo info = {};
+    u64 dictGen = 0;
+    std::vector<ZSTD_DCtx_s*> workers;      // ZSTDMI_DCtx_setDevices (decompress_multi)
 };
 
 
@@ -296,8 +303,50 @@ static size_t cctx_sync_dictionary(ZSTD_CCtx* c)
     return 0;
 }
 
+// How a range of paramSize bytes is cut into blocks and frames (a function of the parameters, the loaded dictionary and that size):
+// bytes of dictionary in front of every chunk, bytes per block, blocks per frame (0 = every block a frame of its own), and what
+// the level resolves to for it.
+struct Framing { u32 prefixLen, chunkBytes, frameBlocks; Resolved rs; size_t span() const { return (size_t)chunkBytes * (frameBlocks ? frameBlocks : 1u); } };
+static Framing resolve_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t paramSize)
+{
+    const u32 prefixLen = cp.useDict ? dict_prefix_len(c, paramSize) : 0u;
+    u32 chunkBytes = kChunkSize - round_tile(prefixLen);
+    // ZSTD_c_windowLog 10 .. 15: independent frames of 1 << windowLog bytes (the reference cuts blocks at the window size and lets
+    // no offset exceed it, U/ZstdCompress.cs:4690-4712, U/ZstdCompressInternal.cs:787-813; a frame that IS its own window does both)
+    if (cp.windowLog >= 10 && cp.windowLog < (int)kChunkLog && chunkBytes > (1u << cp.windowLog)) chunkBytes = 1u << cp.windowLog;
+    Resolved rs = resolve_call(cp, paramSize, chunkBytes);
+    // Cross-chunk history (SURVEY.md 8 f-1; the window the block loop carries, U/ZstdCompress.cs:4705-4807): blocks of 64 KiB - hist
+    // bytes, each with the hist bytes in front of it as match-only history in LDS, frameBlocks of them to a frame (so a
+    // match never reaches out of its frame and frames stay independent units for the decoder and for sharding).  Without a
+    // dictionary only (a dictionary's tail takes the same place in LDS).
+    u32 frameBlocks = 0;
+    // a frame never declares more than the window the caller asked for (its content size is its window)
+    const u32 frameBytes = (cp.windowLog >= (int)kChunkLog && cp.windowLog < 31 && ((u64)1 << cp.windowLog) < c->frameBytes) ? (1u << cp.windowLog) : c->frameBytes;
+    if (prefixLen == 0 && paramSize > kChunkSize && chunkBytes == kChunkSize && frameBytes > kChunkSize) {
+        int hb = c->historyBytes;
+        // by level: the doubleFast levels (3-4; 3 is the library's default level) stage 16 KiB of history per 48 KiB block (one
+        // third more staging and hashing for three quarters of what 32 KiB buy), greedy and above 32 KiB per 32 KiB block
+        if (hb < 0) hb = (rs.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (rs.cp.strategy == kStratDfast ? (16 << 10) : (32 << 10)) : 0;
+        if (hb > 0) {
+            // what the level resolves to at the frame's size decides the form: the fast strategy keeps full 64 KiB blocks and
+            // finds far matches through its table (candidates in front of the block are verified against global memory, up to
+            // 188 KiB back); the dual-hash finders' 16-bit tables cannot hold far positions, so their blocks shrink to
+            // 64 KiB - hist and carry the hist bytes in front of them in LDS
+            const Resolved rf = resolve_call(cp, paramSize < frameBytes ? paramSize : frameBytes, frameBytes);
+            if (rf.finder == 0) chunkBytes = kChunkSize;
+            else { const u32 histB = round_tile((size_t)hb) > (48u << 10) ? (48u << 10) : round_tile((size_t)hb); chunkBytes = kChunkSize - histB; }
+            frameBlocks = frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
+            rs = rf;
+        }
+    }
+    Framing f; f.prefixLen = prefixLen; f.chunkBytes = chunkBytes; f.frameBlocks = frameBlocks; f.rs = rs;
+    return f;
+}
+
 // the compress pipeline over device-resident buffers: one range of the input with one set of parameters (see compress_device)
-static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize, bool& first)
+// paramSize: the size the parameters are resolved for — the whole range's, of which [d_src, d_src + srcSize) may be a frame-aligned
+// part (a device worker's share of the range, compress_multi): what is written for a stretch of frames depends on nothing else
+static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize, size_t paramSize, bool& first)
 {
     hipStream_t s = c->stream;
     if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
@@ -313,42 +362,15 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
         return n;
     }
     if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
-    const u32 prefixLen = cp.useDict ? dict_prefix_len(c, srcSize) : 0u;
-    u32 chunkBytes = kChunkSize - round_tile(prefixLen);
-    // ZSTD_c_windowLog 10 .. 15: independent frames of 1 << windowLog bytes (the reference cuts blocks at the window size and lets
-    // no offset exceed it, U/ZstdCompress.cs:4690-4712, U/ZstdCompressInternal.cs:787-813; a frame that IS its own window does both)
-    if (cp.windowLog >= 10 && cp.windowLog < (int)kChunkLog && chunkBytes > (1u << cp.windowLog)) chunkBytes = 1u << cp.windowLog;
+    const Framing fr = resolve_framing(c, cp, paramSize);
+    const u32 prefixLen = fr.prefixLen, chunkBytes = fr.chunkBytes, frameBlocks = fr.frameBlocks;
+    const Resolved rs = fr.rs;
     // a formatted dictionary: its dictID in every frame header (unless ZSTD_c_dictIDFlag = 0), its repcodes in front of every frame
     const bool fmtDict = cp.useDict && c->dictFormatted;
     const u32 dictID = fmtDict ? c->info.dictID : 0u;
     const u32 dictIdBytes = (dictID && cp.dictIDFlag) ? (dictID < 256 ? 1u : dictID < 65536 ? 2u : 4u) : 0u;
     const u32 plainReps[3] = { 1, 4, 8 };
     const u32* const initReps = fmtDict ? c->info.rep : plainReps;
-    Resolved rs = resolve_call(cp, srcSize, chunkBytes);
-    // Cross-chunk history (SURVEY.md 8 f-1; the window the block loop carries, U/ZstdCompress.cs:4705-4807): blocks of 64 KiB - hist
-    // bytes, each with the hist bytes in front of it as match-only history in LDS, frameBlocks of them to a frame (so a
-    // match never reaches out of its frame and frames stay independent units for the decoder and for sharding).  Without a
-    // dictionary only (a dictionary's tail takes the same place in LDS).
-    u32 frameBlocks = 0;
-    // a frame never declares more than the window the caller asked for (its content size is its window)
-    const u32 frameBytes = (cp.windowLog >= (int)kChunkLog && cp.windowLog < 31 && ((u64)1 << cp.windowLog) < c->frameBytes) ? (1u << cp.windowLog) : c->frameBytes;
-    if (prefixLen == 0 && srcSize > kChunkSize && chunkBytes == kChunkSize && frameBytes > kChunkSize) {
-        int hb = c->historyBytes;
-        // by level: the doubleFast levels (3-4; 3 is the library's default level) stage 16 KiB of history per 48 KiB block (one
-        // third more staging and hashing for three quarters of what 32 KiB buy), greedy and above 32 KiB per 32 KiB block
-        if (hb < 0) hb = (rs.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (rs.cp.strategy == kStratDfast ? (16 << 10) : (32 << 10)) : 0;
-        if (hb > 0) {
-            // what the level resolves to at the frame's size decides the form: the fast strategy keeps full 64 KiB blocks and
-            // finds far matches through its table (candidates in front of the block are verified against global memory, up to
-            // 188 KiB back); the dual-hash finders' 16-bit tables cannot hold far positions, so their blocks shrink to
-            // 64 KiB - hist and carry the hist bytes in front of them in LDS
-            const Resolved rf = resolve_call(cp, srcSize < frameBytes ? srcSize : frameBytes, frameBytes);
-            if (rf.finder == 0) chunkBytes = kChunkSize;
-            else { const u32 histB = round_tile((size_t)hb) > (48u << 10) ? (48u << 10) : round_tile((size_t)hb); chunkBytes = kChunkSize - histB; }
-            frameBlocks = frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
-            rs = rf;
-        }
-    }
     const u8* prefix = prefixLen ? (const u8*)c->dict.p + (c->dictHost.size() - prefixLen) : nullptr;
     const u64 totalChunks = (srcSize + chunkBytes - 1) / chunkBytes;
     u32 passChunks = (u32)(totalChunks < c->passChunks ? totalChunks : c->passChunks);
@@ -395,61 +417,48 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
     return produced;
 }
 
-// Level >= 3 framing of a call that leaves strategy, window and history to the level: (block bytes, blocks per frame)
-static void level_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t srcSize, u32& chunkBytes, u32& frameBlocks)
-{
-    const Resolved r0 = resolve_call(cp, srcSize, kChunkSize);
-    chunkBytes = kChunkSize; frameBlocks = 0;
-    const int hb = (r0.cp.strategy > kStratFast || cp.windowLog > (int)kChunkLog) ? (r0.cp.strategy == kStratDfast ? (16 << 10) : (32 << 10)) : 0;
-    if (hb <= 0 || srcSize <= kChunkSize) return;
-    const Resolved rf = resolve_call(cp, srcSize < c->frameBytes ? srcSize : c->frameBytes, c->frameBytes);      // (the probe runs only when windowLog is left to the level)
-    if (rf.finder != 0) chunkBytes = kChunkSize - round_tile((size_t)hb);
-    frameBlocks = c->frameBytes / chunkBytes; if (frameBlocks < 2) frameBlocks = 2;
-}
-
 // Input the match finder gets nothing out of (BASELINE's Zipf bytes, random or already compressed data): the history, smaller blocks
 // and deeper search of the levels >= 3 only cost there — Zipf at level 5 came out 0.8 % LARGER than at level 1 (a frame header share
 // and a Huffman table per 32 KiB instead of per 64 KiB) at an eighth of the speed, and in a mixed input such stretches took a third
 // of the match finder's time.  So a call of 4 MiB or more that leaves strategy, window and history to the level is first looked at
 // in groups of 16 frames (~4 MiB): lz_probe_kernel counts, in eight 4 KiB tiles per group, the positions that repeat an earlier one of
-// their tile (text: several hundred per tile; Zipf bytes: a handful; ~40 us per GiB with the read-back).  Runs of groups below 32
-// per tile — the whole call, or at least 64 MiB of it — are compressed as level 1 would (its finder, independent 64 KiB frames: the
-// same bytes level 1 writes for them), the rest by the level's own path; a group boundary is a frame boundary of both.  The decision
-// is a function of the data alone.
-static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+// their tile or of the 60 KiB in front of it (text: several hundred per tile; Zipf bytes: a handful; an eighth of the input is read).
+// Runs of groups below 32 per tile — the whole call, or at least 64 MiB of it — are compressed as level 1 would (its finder,
+// independent 64 KiB frames: the same bytes level 1 writes for them), the rest by the level's own path; a group boundary is a frame
+// boundary of both.  The decision is a function of the data alone: probe (device, per group) -> plan (host) -> ranges.
+constexpr u32 kProbeTiles = 8;
+struct PlanRange { size_t off, len; bool sparse; };
+
+// does the call get probed, and in groups of how many bytes?  (0 = no probe: one range, the call's own parameters)
+static size_t probe_group_bytes(ZSTD_CCtx* c, const CallParams& cp, size_t srcSize, size_t& err)
 {
-    bool first = true;
-    if (cp.minMatch || cp.chainLog) {       // set under another level or strategy than the call runs with: refuse, never ignore
-        const CParams lv = get_cparams(cp.level, kChunkSize);
-        if (cp.minMatch && cp.minMatch != (int)kernel_min_match(cp.strategy ? (u32)cp.strategy : lv.strategy)) return ZERR(kErrParameterUnsupported);
-        if (cp.chainLog && cp.chainLog != (int)lv.chainLog) return ZERR(kErrParameterUnsupported);
-    }
+    err = 0;
     // (a caller-set targetLength keeps the level's own path: at the fast strategy it means raw literals, which the sparse ranges must not inherit)
-    bool probe = srcSize >= (4u << 20) && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0 && cp.targetLength == 0;
-    if (probe) {
-        if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
-        if (cp.useDict && dict_prefix_len(c, srcSize)) probe = false;
-        else if (resolve_call(cp, srcSize, kChunkSize).cp.strategy <= kStratFast) probe = false;
-    }
-    if (!probe) return compress_range(c, cp, d_dst, dstCapacity, d_src, srcSize, first);
-    u32 chunkBytes, frameBlocks;
-    level_framing(c, cp, srcSize, chunkBytes, frameBlocks);
-    const size_t group = (size_t)16 * (frameBlocks ? (size_t)frameBlocks * chunkBytes : (size_t)kChunkSize * 4);      // a multiple of 64 KiB
-    const u32 nGroups = (u32)((srcSize + group - 1) / group);
-    constexpr u32 kTilesPerGroup = 8;
+    if (!(srcSize >= (4u << 20) && c->historyBytes < 0 && cp.strategy == 0 && cp.windowLog == 0 && cp.searchLog == 0 && cp.targetLength == 0)) return 0;
+    if (cp.useDict) { err = cctx_sync_dictionary(c); if (isErr(err)) return 0; err = 0; }
+    if (cp.useDict && dict_prefix_len(c, srcSize)) return 0;
+    if (resolve_call(cp, srcSize, kChunkSize).cp.strategy <= kStratFast) return 0;
+    const Framing fr = resolve_framing(c, cp, srcSize);
+    return (size_t)16 * (fr.frameBlocks ? fr.span() : (size_t)kChunkSize * 4);      // a multiple of 64 KiB
+}
+// counts of the groups of [d_src, d_src + len); `front` = bytes of the input readable in front of d_src (a worker's share of a call)
+static size_t probe_run(ZSTD_CCtx* c, const u8* d_src, size_t len, size_t front, size_t group, u32* counts)
+{
+    const u32 nGroups = (u32)((len + group - 1) / group);
     if (!c->probe.ensure((size_t)nGroups * sizeof(u32))) return ZERR(kErrMemoryAllocation);
-    launch_lz_probe(d_src, srcSize, group, nGroups, kTilesPerGroup, (u32*)c->probe.p, c->stream);
-    std::vector<u32> counts;
-    try { counts.resize(nGroups); } catch (...) { return ZERR(kErrMemoryAllocation); }
-    if (hipMemcpyAsync(counts.data(), c->probe.p, (size_t)nGroups * sizeof(u32), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZERR(kErrGeneric);
+    launch_lz_probe(d_src, len, front, group, nGroups, kProbeTiles, (u32*)c->probe.p, c->stream);
+    if (hipMemcpyAsync(counts, c->probe.p, (size_t)nGroups * sizeof(u32), hipMemcpyDeviceToHost, c->stream) != hipSuccess) return ZERR(kErrGeneric);
     if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
-    CallParams cpSparse = cp; cpSparse.level = 1;
+    return 0;
+}
+static void plan_ranges(const std::vector<u32>& counts, size_t group, size_t srcSize, std::vector<PlanRange>& out)
+{
+    const u32 nGroups = (u32)counts.size();
     // a range is a pass of its own, and a pass needs thousands of chunks to fill the chip (the entropy stage walks serial chains per
     // chunk): a stretch without matches counts only if it is the whole call or at least 64 MiB long — measured on the mixed bench
     // input, whose 6.4 MiB pieces as ranges of their own took 1.7 x the time of one pass over everything
-    std::vector<u8> sp;
-    try { sp.resize(nGroups); } catch (...) { return ZERR(kErrMemoryAllocation); }
-    for (u32 g = 0; g < nGroups; ++g) sp[g] = counts[g] < kTilesPerGroup * 32;
+    std::vector<u8> sp(nGroups);
+    for (u32 g = 0; g < nGroups; ++g) sp[g] = counts[g] < kProbeTiles * 32;
     const u32 minRun = (u32)(((size_t)64 << 20) / group);
     for (u32 g = 0; g < nGroups; ) {
         u32 e = g + 1;
@@ -457,19 +466,63 @@ static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, siz
         if (sp[g] && e - g < minRun && !(g == 0 && e == nGroups)) for (u32 k = g; k < e; ++k) sp[k] = 0;
         g = e;
     }
-    size_t produced = 0;
     for (u32 g = 0; g < nGroups; ) {
         const bool sparse = sp[g] != 0;
         u32 e = g + 1;
         while (e < nGroups && (sp[e] != 0) == sparse) ++e;
-        const size_t off = (size_t)g * group, len = (e == nGroups ? srcSize : (size_t)e * group) - off;
-        const size_t r = compress_range(c, sparse ? cpSparse : cp, d_dst + produced, dstCapacity > produced ? dstCapacity - produced : 0, d_src + off, len, first);
-        if (isErr(r)) return r;
-        produced += r;
+        PlanRange r; r.off = (size_t)g * group; r.len = (e == nGroups ? srcSize : (size_t)e * group) - r.off; r.sparse = sparse;
+        out.push_back(r);
         g = e;
+    }
+}
+static size_t check_call_params(const CallParams& cp)
+{
+    if (cp.minMatch || cp.chainLog) {       // set under another level or strategy than the call runs with: refuse, never ignore
+        const CParams lv = get_cparams(cp.level, kChunkSize);
+        if (cp.minMatch && cp.minMatch != (int)kernel_min_match(cp.strategy ? (u32)cp.strategy : lv.strategy)) return ZERR(kErrParameterUnsupported);
+        if (cp.chainLog && cp.chainLog != (int)lv.chainLog) return ZERR(kErrParameterUnsupported);
+    }
+    return 0;
+}
+
+static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+{
+    bool first = true;
+    { const size_t e = check_call_params(cp); if (isErr(e)) return e; }
+    size_t err = 0;
+    const size_t group = probe_group_bytes(c, cp, srcSize, err);
+    if (isErr(err)) return err;
+    if (!group) return compress_range(c, cp, d_dst, dstCapacity, d_src, srcSize, srcSize, first);
+    std::vector<u32> counts((srcSize + group - 1) / group);
+    { const size_t e = probe_run(c, d_src, srcSize, 0, group, counts.data()); if (isErr(e)) return e; }
+    std::vector<PlanRange> plan;
+    plan_ranges(counts, group, srcSize, plan);
+    CallParams cpSparse = cp; cpSparse.level = 1;
+    size_t produced = 0;
+    for (const PlanRange& r : plan) {
+        const size_t n = compress_range(c, r.sparse ? cpSparse : cp, d_dst + produced, dstCapacity > produced ? dstCapacity - produced : 0, d_src + r.off, r.len, r.len, first);
+        if (isErr(n)) return n;
+        produced += n;
     }
     return produced;
 }
+
+// run f(0 .. n - 1), one host thread each (f(0) on the caller's): a device worker's calls block on its own stream
+// (nothing may leave a thread as an exception: -> false, and the caller reports memory_allocation)
+template <class F> static bool run_on_workers(size_t n, F f)
+{
+    std::vector<std::thread> th;
+    std::vector<u8> bad(n, 0);
+    th.reserve(n);
+    auto one = [&f, &bad](size_t i) { try { f(i); } catch (...) { bad[i] = 1; } };
+    bool ok = true;
+    for (size_t i = 1; i < n; ++i) { try { th.emplace_back(one, i); } catch (...) { ok = false; break; } }
+    if (ok) one(0);
+    for (auto& t : th) t.join();
+    for (size_t i = 0; i < n; ++i) ok = ok && !bad[i];
+    return ok;
+}
+static size_t compress_multi(ZSTD_CCtx* c, const CallParams& cp, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 
 // ======================================================================================================
 extern "C" {
@@ -479,6 +532,8 @@ ZSTD_CCtx* ZSTD_createCCtx(void) { return new (std::nothrow) ZSTD_CCtx_s(); }
 size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
 {
     if (!c) return 0;
+    for (ZSTD_CCtx* w : c->workers) (void)ZSTD_freeCCtx(w);
+    c->workers.clear();
     if (c->deviceOk) {
         (void)hipSetDevice(c->device);
         if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
@@ -568,6 +623,7 @@ static size_t ZSTD_CCtx_loadDictionary_impl(ZSTD_CCtx* c, const void* dict, size
 {
     if (!c) return ZERR(kErrGeneric);
     if (!c->sIn.empty() || c->sEnding) return ZERR(kErrStageWrong);        /* not in the middle of a streaming frame session, U/ZstdCompress.cs:1273 */
+    c->dictGen++;
     c->dictFormatted = false; c->dictFull.clear();
     if (dict == nullptr || dictSize == 0) { c->dictHost.clear(); c->dictDirty = true; return 0; }          /* "no dictionary" */
     if (dictSize > (size_t)1 << 30) return ZERR(kErrParameterUnsupported);
@@ -596,12 +652,13 @@ static size_t ZSTD_CCtx_loadDictionary_impl(ZSTD_CCtx* c, const void* dict, size
 
 size_t ZSTD_compressBound(size_t n) { return n + (n >> 8) + (n < (128u << 10) ? (((128u << 10) - n) >> 11) : 0); }
 
-size_t ZSTDMI_compressDevice(ZSTD_CCtx* c, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
+static size_t ZSTDMI_compressDevice_impl(ZSTD_CCtx* c, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
 {
     size_t e = cctx_bind(c); if (isErr(e)) return e;
     if (srcSize && !d_src) return ZERR(kErrSrcSizeWrong);
     if (!d_dst && dstCapacity) return ZERR(kErrDstBufferNull);
     if (!d_dst) return ZERR(kErrDstSizeTooSmall);
+    if (c->workers.size() > 1 && srcSize) return compress_multi(c, sticky_params(c), d_dst, dstCapacity, d_src, srcSize);
     return compress_device(c, sticky_params(c), (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
 }
 
@@ -610,6 +667,7 @@ static size_t compress_any(ZSTD_CCtx* c, const CallParams& cp, void* dst, size_t
     size_t e = cctx_bind(c); if (isErr(e)) return e;
     if (srcSize && !src) return ZERR(kErrSrcSizeWrong);
     if (!dst) return ZERR(kErrDstSizeTooSmall);
+    if (c->workers.size() > 1 && srcSize) return compress_multi(c, cp, dst, dstCapacity, src, srcSize);
     const bool srcDev = srcSize ? is_device_ptr(src) : true, dstDev = is_device_ptr(dst);
     const u8* d_src = (const u8*)src; u8* d_dst = (u8*)dst;
     size_t devCap = dstCapacity;
@@ -633,10 +691,11 @@ static size_t compress_any(ZSTD_CCtx* c, const CallParams& cp, void* dst, size_t
     return r;
 }
 
+size_t ZSTDMI_compressDevice(ZSTD_CCtx* c, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize) { return guarded([&] { return ZSTDMI_compressDevice_impl(c, d_dst, dstCapacity, d_src, srcSize); }); }
 size_t ZSTD_compress2(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
 {
     if (!c) return ZERR(kErrGeneric);
-    return compress_any(c, sticky_params(c), dst, dstCapacity, src, srcSize);
+    return guarded([&] { return compress_any(c, sticky_params(c), dst, dstCapacity, src, srcSize); });
 }
 
 size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void* src, size_t srcSize, int level)
@@ -647,7 +706,7 @@ size_t ZSTD_compressCCtx(ZSTD_CCtx* c, void* dst, size_t dstCapacity, const void
     // its dictionary stay as they are for later ZSTD_compress2 calls.
     CallParams p; p.level = level == 0 ? 3 : (level < ZSTD_minCLevel() ? ZSTD_minCLevel() : level > ZSTD_maxCLevel() ? ZSTD_maxCLevel() : level);
     p.useDict = false;
-    return compress_any(c, p, dst, dstCapacity, src, srcSize);
+    return guarded([&] { return compress_any(c, p, dst, dstCapacity, src, srcSize); });
 }
 
 /* S/CompressionStream.cs:41, S/DecompressionStream.cs:41 size their buffers with these (U/ZstdCompress.cs:6241-6249,
@@ -662,6 +721,8 @@ ZSTD_DCtx* ZSTD_createDCtx(void) { return new (std::nothrow) ZSTD_DCtx_s(); }
 size_t ZSTD_freeDCtx(ZSTD_DCtx* d)
 {
     if (!d) return 0;
+    for (ZSTD_DCtx* w : d->workers) (void)ZSTD_freeDCtx(w);
+    d->workers.clear();
     if (d->deviceOk) {
         (void)hipSetDevice(d->device);
         if (d->ownStream) (void)hipStreamSynchronize(d->ownStream);
@@ -692,6 +753,7 @@ size_t ZSTD_DCtx_getParameter(ZSTD_DCtx* d, int param, int* value)
 static size_t ZSTD_DCtx_loadDictionary_impl(ZSTD_DCtx* d, const void* dict, size_t dictSize)
 {
     if (!d) return ZERR(kErrGeneric);
+    d->dictGen++;
     if (dict == nullptr || dictSize == 0) { d->dictHost.clear(); d->dictDirty = true; return 0; }
     if (dictSize > (size_t)1 << 30) return ZERR(kErrParameterUnsupported);
     std::vector<u8> h(dictSize);
@@ -968,10 +1030,12 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     return (size_t)total;
 }
 
+static size_t decompress_multi(ZSTD_DCtx* d, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 static size_t ZSTDMI_decompressDevice_impl(ZSTD_DCtx* d, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize)
 {
     size_t e = dctx_bind(d); if (isErr(e)) return e;
     if (srcSize && !d_src) return ZERR(kErrSrcSizeWrong);
+    if (d->workers.size() > 1 && srcSize) return decompress_multi(d, d_dst, dstCapacity, d_src, srcSize);
     return decompress_device(d, (u8*)d_dst, dstCapacity, (const u8*)d_src, srcSize);
 }
 
@@ -980,6 +1044,7 @@ static size_t ZSTD_decompressDCtx_impl(ZSTD_DCtx* d, void* dst, size_t dstCapaci
     size_t e = dctx_bind(d); if (isErr(e)) return e;
     if (srcSize && !src) return ZERR(kErrSrcSizeWrong);
     if (srcSize == 0) return 0;
+    if (d->workers.size() > 1) return decompress_multi(d, dst, dstCapacity, src, srcSize);
     const bool srcDev = is_device_ptr(src), dstDev = dst ? is_device_ptr(dst) : false;
     const u8* d_src = (const u8*)src; u8* d_dst = (u8*)dst;
     if (!srcDev) {
@@ -998,6 +1063,176 @@ static size_t ZSTD_decompressDCtx_impl(ZSTD_DCtx* d, void* dst, size_t dstCapaci
         if (hipStreamSynchronize(d->stream) != hipSuccess) return ZERR(kErrGeneric);
     }
     return r;
+}
+
+// ---------------- several devices behind one context (SURVEY.md section 8 e; ZSTDMI_*_setDevices) ----------------
+// north_star: "chunks partition naturally across the 8 GPUs of one node".  Frames are the independent unit (a match never leaves its
+// frame), so a call's frames are dealt to the device workers in contiguous shares: every worker stages its share on its own device,
+// compresses it with the kernels above on its own stream, from a host thread of its own, and the shares' outputs are copied into the
+// caller's buffer one behind the other.  What is written does not depend on the number of workers: shares are cut on frame
+// boundaries (on probe-group boundaries when the sparse-input probe runs), parameters are resolved for the whole range, and the probe's
+// plan is made once over all shares' counts.  No collective: the only exchange is the final copy (device to host, or peer to peer).
+static size_t copy_any(void* dst, const void* src, size_t n, hipStream_t s)
+{
+    if (!n) return 0;
+    if (hipMemcpyAsync(dst, src, n, hipMemcpyDefault, s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    return 0;
+}
+
+static size_t compress_multi(ZSTD_CCtx* c, const CallParams& cp, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    { const size_t e = check_call_params(cp); if (isErr(e)) return e; }
+    const size_t W = c->workers.size();
+    bool ok = true;
+    // the workers run with the parent's settings and dictionary
+    if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
+    for (ZSTD_CCtx* w : c->workers) {
+        w->historyBytes = c->historyBytes; w->frameBytes = c->frameBytes; w->parser = c->parser; w->passChunks = c->passChunks; w->timer.enabled = c->timer.enabled;
+        if (w->dictGen != c->dictGen) {
+            w->dictHost = c->dictHost; w->dictFull = c->dictFull; w->dictFormatted = c->dictFormatted; w->info = c->info; w->dictDirty = true; w->dictGen = c->dictGen;
+        }
+    }
+    size_t err = 0;
+    ZSTD_CCtx* const w0 = c->workers[0];
+    { const size_t e = cctx_bind(w0); if (isErr(e)) return e; }
+    if (cp.useDict) { const size_t e = cctx_sync_dictionary(w0); if (isErr(e)) return e; }
+    const size_t group = probe_group_bytes(w0, cp, srcSize, err);
+    if (isErr(err)) return err;
+    // shares: whole probe groups, or whole frames of the one range
+    const size_t unit = group ? group : resolve_framing(w0, cp, srcSize).span();
+    const size_t nUnits = (srcSize + unit - 1) / unit;
+    std::vector<size_t> lo(W + 1);
+    for (size_t i = 0; i <= W; ++i) { const size_t u = nUnits * i / W; lo[i] = u * unit < srcSize ? u * unit : srcSize; }
+    lo[W] = srcSize;
+    std::vector<size_t> res(W, 0), front(W, 0);
+    std::vector<u32> counts(group ? (srcSize + group - 1) / group : 0);
+    // phase A: every worker stages its share (with the probe's 60 KiB window in front of it) and, if the call is probed, counts its groups
+    ok = run_on_workers(W, [&](size_t i) {
+        ZSTD_CCtx* w = c->workers[i];
+        size_t e = cctx_bind(w); if (isErr(e)) { res[i] = e; return; }
+        const size_t n = lo[i + 1] - lo[i];
+        if (!n) return;
+        front[i] = group ? (lo[i] < (60u << 10) ? lo[i] : (60u << 10)) : 0;
+        if (!w->stageSrc.ensure(front[i] + n + 64) || !w->stageDst.ensure(ZSTD_compressBound(n) + (n / unit + 2) * 64 + 64)) { res[i] = ZERR(kErrMemoryAllocation); return; }
+        e = copy_any(w->stageSrc.p, (const u8*)src + lo[i] - front[i], front[i] + n, w->stream); if (isErr(e)) { res[i] = e; return; }
+        if (group) { e = probe_run(w, (const u8*)w->stageSrc.p + front[i], n, front[i], group, counts.data() + lo[i] / group); if (isErr(e)) res[i] = e; }
+    });
+    if (!ok) return ZERR(kErrMemoryAllocation);
+    for (size_t i = 0; i < W; ++i) if (isErr(res[i])) return res[i];
+    std::vector<PlanRange> plan;
+    if (group) plan_ranges(counts, group, srcSize, plan);
+    else { PlanRange r; r.off = 0; r.len = srcSize; r.sparse = false; plan.push_back(r); }
+    CallParams cpSparse = cp; cpSparse.level = 1;
+    // phase B: every worker compresses what the plan's ranges hold of its share
+    std::vector<size_t> produced(W, 0);
+    ok = run_on_workers(W, [&](size_t i) {
+        ZSTD_CCtx* w = c->workers[i];
+        if (isErr(cctx_bind(w))) return;
+        bool first = true;
+        for (const PlanRange& r : plan) {
+            const size_t a = r.off > lo[i] ? r.off : lo[i], b = (r.off + r.len) < lo[i + 1] ? (r.off + r.len) : lo[i + 1];
+            if (a >= b) continue;
+            const size_t n = compress_range(w, r.sparse ? cpSparse : cp, (u8*)w->stageDst.p + produced[i], w->stageDst.cap - produced[i],
+                                            (const u8*)w->stageSrc.p + front[i] + (a - lo[i]), b - a, r.len, first);
+            if (isErr(n)) { res[i] = n; return; }
+            produced[i] += n;
+        }
+    });
+    if (!ok) return ZERR(kErrMemoryAllocation);
+    for (size_t i = 0; i < W; ++i) if (isErr(res[i])) return res[i];
+    size_t total = 0;
+    for (size_t i = 0; i < W; ++i) total += produced[i];
+    if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
+    // the shares, one behind the other, into the caller's buffer (host: device-to-host copies side by side; device: peer copies)
+    std::vector<size_t> at(W, 0);
+    for (size_t i = 1; i < W; ++i) at[i] = at[i - 1] + produced[i - 1];
+    ok = run_on_workers(W, [&](size_t i) {
+        ZSTD_CCtx* w = c->workers[i];
+        if (isErr(cctx_bind(w))) return;
+        size_t e = copy_any((u8*)dst + at[i], w->stageDst.p, produced[i], w->stream);
+        if (!isErr(e) && hipStreamSynchronize(w->stream) != hipSuccess) { (void)hipGetLastError(); e = ZERR(kErrGeneric); }
+        if (isErr(e)) res[i] = e;
+    });
+    if (!ok) return ZERR(kErrMemoryAllocation);
+    for (size_t i = 0; i < W; ++i) if (isErr(res[i])) return res[i];
+    // stage times: the first worker's (every worker runs the same sequence over its share)
+    c->nStages = w0->nStages;
+    for (int i = 0; i < w0->nStages; i++) { c->stageMs[i] = w0->stageMs[i]; c->stageNames[i] = w0->stageNames[i]; }
+    c->lastChunks = 0;
+    (void)cctx_bind(c);
+    return total;
+}
+
+// decompress: the frames of the input (a host-side header walk) in contiguous shares by compressed size
+static size_t decompress_multi(ZSTD_DCtx* d, void* dst, size_t dstCapacity, const void* src, size_t srcSize)
+{
+    const size_t W = d->workers.size();
+    bool ok = true;
+    std::vector<u8> tmp;
+    const u8* const ip = host_view(src, srcSize, tmp);
+    if (!ip) return ZERR(kErrGeneric);
+    struct Piece { size_t off, len; unsigned long long bound; bool sized; };
+    std::vector<Piece> frames;
+    { size_t pos = 0;
+      while (pos < srcSize) {
+          unsigned long long b = 0; const size_t fs = host_frame_size_info(ip + pos, srcSize - pos, &b);
+          if (isErr(fs)) { if (frames.empty() || fs != ZERR(kErrPrefixUnknown)) return fs; return ZERR(kErrSrcSizeWrong); }     // as ZSTD_decompressMultiFrame: garbage behind a frame
+          Piece p; p.off = pos; p.len = fs; p.bound = b;
+          p.sized = ZSTD_getFrameContentSize_impl(ip + pos, fs) < (unsigned long long)0 - 2;
+          frames.push_back(p); pos += fs;
+      } }
+    // shares of about equal compressed size
+    std::vector<size_t> lo(W + 1, frames.size());
+    { size_t acc = 0, k = 0; lo[0] = 0;
+      for (size_t f = 0; f < frames.size(); ++f) { while (k + 1 < W && acc >= srcSize * (k + 1) / W) lo[++k] = f; acc += frames[f].len; }
+      while (k + 1 < W) lo[++k] = frames.size(); lo[W] = frames.size(); }
+    std::vector<size_t> res(W, 0), got(W, 0);
+    std::vector<unsigned long long> bound(W, 0);
+    bool allSized = true;
+    for (size_t i = 0; i < W; ++i) for (size_t f = lo[i]; f < lo[i + 1]; ++f) { bound[i] += frames[f].bound; allSized = allSized && frames[f].sized; }
+    if (allSized) { unsigned long long t = 0; for (size_t i = 0; i < W; ++i) t += bound[i]; if (t > dstCapacity) return ZERR(kErrDstSizeTooSmall); }
+    { const size_t e = dctx_sync_dictionary(d); if (isErr(e)) return e; }
+    for (ZSTD_DCtx* w : d->workers) {
+        w->litDecoder = d->litDecoder; w->originMode = d->originMode; w->overlapMode = d->overlapMode; w->timer.enabled = d->timer.enabled;
+        if (w->dictGen != d->dictGen) { w->dictHost = d->dictHost; w->dictFormatted = d->dictFormatted; w->dictDirty = true; w->dictGen = d->dictGen; }
+    }
+    std::vector<size_t> at(W, 0);
+    for (size_t i = 1; i < W; ++i) at[i] = at[i - 1] + (size_t)bound[i - 1];       // exact when every frame has a content size
+    ok = run_on_workers(W, [&](size_t i) {
+        ZSTD_DCtx* w = d->workers[i];
+        size_t e = dctx_bind(w); if (isErr(e)) { res[i] = e; return; }
+        if (lo[i] == lo[i + 1]) return;
+        const size_t a = frames[lo[i]].off, n = frames[lo[i + 1] - 1].off + frames[lo[i + 1] - 1].len - a;
+        if (!w->stageSrc.ensure(n + 64) || !w->stageDst.ensure((size_t)bound[i] + 64)) { res[i] = ZERR(kErrMemoryAllocation); return; }
+        e = copy_any(w->stageSrc.p, ip + a, n, w->stream); if (isErr(e)) { res[i] = e; return; }
+        const size_t r = decompress_device(w, (u8*)w->stageDst.p, (size_t)bound[i], (const u8*)w->stageSrc.p, n);
+        if (isErr(r)) { res[i] = r; return; }
+        got[i] = r;
+        if (allSized) {         // its place in the caller's buffer is known
+            e = copy_any((u8*)dst + at[i], w->stageDst.p, r, w->stream);
+            if (!isErr(e) && hipStreamSynchronize(w->stream) != hipSuccess) { (void)hipGetLastError(); e = ZERR(kErrGeneric); }
+            if (isErr(e)) res[i] = e;
+        }
+    });
+    if (!ok) return ZERR(kErrMemoryAllocation);
+    for (size_t i = 0; i < W; ++i) if (isErr(res[i])) return res[i];          // the first share's error is the first frame's
+    size_t total = 0;
+    for (size_t i = 0; i < W; ++i) total += got[i];
+    if (!allSized) {            // frames without a content size: the shares' places follow from what they regenerated
+        if (total > dstCapacity) return ZERR(kErrDstSizeTooSmall);
+        size_t pos = 0;
+        for (size_t i = 0; i < W; ++i) {
+            ZSTD_DCtx* w = d->workers[i];
+            if (isErr(dctx_bind(w))) return ZERR(kErrGeneric);
+            const size_t e = copy_any((u8*)dst + pos, w->stageDst.p, got[i], w->stream); if (isErr(e)) return e;
+            if (hipStreamSynchronize(w->stream) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+            pos += got[i];
+        }
+    }
+    d->timer.n = d->workers[0]->timer.n;
+    for (int i = 0; i < d->timer.n; i++) { d->timer.ms[i] = d->workers[0]->timer.ms[i]; d->timer.names[i] = d->workers[0]->timer.names[i]; }
+    (void)dctx_bind(d);
+    return total;
 }
 
 // ---------------- errors ----------------
@@ -1155,6 +1390,37 @@ static size_t ZSTD_decompressStream_impl(ZSTD_DCtx* d, ZSTD_outBuffer* output, Z
 int ZSTDMI_deviceCount(void) { return device_count(); }
 size_t ZSTDMI_CCtx_setDevice(ZSTD_CCtx* c, int device) { if (!c) return ZERR(kErrGeneric); if (c->deviceOk && device != c->device) return ZERR(kErrStageWrong); c->device = device; return 0; }
 size_t ZSTDMI_DCtx_setDevice(ZSTD_DCtx* d, int device) { if (!d) return ZERR(kErrGeneric); if (d->deviceOk && device != d->device) return ZERR(kErrStageWrong); d->device = device; return 0; }
+// devices: one worker per entry (an ordinal may repeat: several workers share that device); n <= 1 = back to the context's own device
+size_t ZSTDMI_CCtx_setDevices(ZSTD_CCtx* c, const int* devices, int n)
+{
+    if (!c || n < 0 || n > 64 || (n && !devices)) return ZERR(kErrParameterOutOfBound);
+    for (int i = 0; i < n; ++i) if (devices[i] < 0 || devices[i] >= device_count()) return ZERR(kErrInitMissing);
+    for (ZSTD_CCtx* w : c->workers) (void)ZSTD_freeCCtx(w);
+    c->workers.clear();
+    if (n <= 1) { if (n == 1) return ZSTDMI_CCtx_setDevice(c, devices[0]); return 0; }
+    for (int i = 0; i < n; ++i) {
+        ZSTD_CCtx* w = ZSTD_createCCtx();
+        if (!w) return ZERR(kErrMemoryAllocation);
+        w->device = devices[i]; w->dictGen = ~(u64)0;
+        c->workers.push_back(w);
+    }
+    return 0;
+}
+size_t ZSTDMI_DCtx_setDevices(ZSTD_DCtx* d, const int* devices, int n)
+{
+    if (!d || n < 0 || n > 64 || (n && !devices)) return ZERR(kErrParameterOutOfBound);
+    for (int i = 0; i < n; ++i) if (devices[i] < 0 || devices[i] >= device_count()) return ZERR(kErrInitMissing);
+    for (ZSTD_DCtx* w : d->workers) (void)ZSTD_freeDCtx(w);
+    d->workers.clear();
+    if (n <= 1) { if (n == 1) return ZSTDMI_DCtx_setDevice(d, devices[0]); return 0; }
+    for (int i = 0; i < n; ++i) {
+        ZSTD_DCtx* w = ZSTD_createDCtx();
+        if (!w) return ZERR(kErrMemoryAllocation);
+        w->device = devices[i]; w->dictGen = ~(u64)0;
+        d->workers.push_back(w);
+    }
+    return 0;
+}
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->overlapMode = (int)mode; return 0; }
