@@ -53,6 +53,11 @@ def test_shard_ranges_partition_the_input():
             for (a, b), (c, d) in zip(edges, edges[1:]):
                 assert b == c and a <= b
             assert all(lo % 65536 == 0 for lo, _ in edges)
+    from zstdsharp_amd.dist import frame_span
+    for level, span in ((1, 65536), (3, 245760), (5, 262144)):
+        assert frame_span(level) == span
+        edges = [shard_range(10_000_000, r, 3, 16 * span) for r in range(3)]
+        assert edges[0][0] == 0 and edges[-1][1] == 10_000_000 and all(lo % span == 0 for lo, _ in edges)
 
 
 def test_all_gather_v_world2_gloo():

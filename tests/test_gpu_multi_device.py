@@ -90,3 +90,20 @@ def test_worker_errors_and_bounds(gpu_lib, oracle):
         ok, n = d.TryUnwrap(comp, bytearray(1000))
         assert not ok
         assert d.Unwrap(comp) == data
+
+
+@pytest.mark.parametrize("level", [1, 5])
+def test_rank_shards_concatenate_to_the_one_gpu_stream(gpu_lib, oracle, level):
+    """The torch.distributed path (bench.py --gpus N, zstdsharp_amd/dist.py): rank r compresses shard_range(total, r, N, unit) by
+    itself and the all-gather-v puts the outputs one behind the other.  With the unit a multiple of the level's frame span (16 spans
+    where the sparse-input probe groups frames) that concatenation IS what one GPU writes for the whole input — same plan, same frames."""
+    from zstdsharp_amd.dist import frame_span, shard_range
+    data = datagen.gen("text", 21_000_001, 4)
+    with z.Compressor(level) as c:
+        whole = c.Wrap(data)
+        for world in (2, 4):
+            parts = []
+            for r in range(world):
+                lo, hi = shard_range(len(data), r, world, 16 * frame_span(level))
+                parts.append(c.Wrap(data[lo:hi]))
+            assert b"".join(parts) == whole, (level, world)

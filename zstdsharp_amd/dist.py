@@ -11,8 +11,17 @@ import torch.distributed as dist
 CHUNK = 65536
 
 
+def frame_span(level: int) -> int:
+    """Input bytes per frame the library writes at `level` with its default framing: independent 64 KiB frames at the fast strategy
+    (levels <= 2), five 48 KiB blocks at the doubleFast levels (3-4), eight 32 KiB blocks from level 5 on.  Shards cut on multiples
+    of it so that the ranks' outputs, one behind the other, are the stream one GPU writes.  (Calls of 4 MiB or more at levels >= 3
+    are first looked at in groups of 16 frames — the sparse-input probe —, so shards there are cut on 16 spans.)"""
+    return CHUNK if level < 3 else 5 * (48 << 10) if level < 5 else 256 << 10
+
+
 def shard_range(total_bytes: int, rank: int, world: int, chunk: int = CHUNK):
-    """Byte range [lo, hi) of `total_bytes` owned by `rank`: whole chunks, contiguous, in rank order."""
+    """Byte range [lo, hi) of `total_bytes` owned by `rank`: whole units of `chunk` bytes (a frame's span, see frame_span),
+    contiguous, in rank order."""
     k = (total_bytes + chunk - 1) // chunk
     lo_c, hi_c = rank * k // world, (rank + 1) * k // world
     return min(lo_c * chunk, total_bytes), min(hi_c * chunk, total_bytes)
