@@ -253,3 +253,30 @@ def test_a_long_stretch_without_matches_inside_a_call_is_compressed_as_level_1_w
         out = c5.Wrap(short)
         assert out != c1.Wrap(short[:8 << 20]) + c5.Wrap(dense)
         assert walk_frames(gpu_lib, out)[0][0] == (256 << 10) and len(walk_frames(gpu_lib, out)[0][1]) == 8
+
+
+@pytest.mark.parametrize("kind,n", [("text", 10 << 20), ("mixed", 3 << 20), ("text", 65537), ("runs", 200000), ("zipf", 1 << 20), ("text", (32 << 20))])
+def test_small_calls_get_short_blocks_in_64_kib_frames(gpu_lib, oracle, kind, n):
+    """Level 1, 64 KiB < size <= 32 MiB, everything left to the level: frames stay 64 KiB (match execution is ordered per frame) but
+    hold four 16 KiB blocks, each matching into the frame's earlier blocks — four times as many serial chains (tANS, Huffman) a
+    quarter as long, which is what a call of this size waits for.  The price in size against single-block 64 KiB frames is small
+    (block header, Huffman table and the unknown-repcode start per 16 KiB); calls above 32 MiB keep single-block frames."""
+    data = datagen.gen(kind, n, 17)
+    with z.Compressor(1) as c, z.Decompressor() as d:
+        comp = c.Wrap(data)
+        set_history(gpu_lib, c, 0)
+        single = c.Wrap(data)
+    assert oracle.decompress(comp, n) == data
+    with z.Decompressor() as d:
+        assert d.Unwrap(comp) == data
+    frames = walk_frames(gpu_lib, comp)
+    assert all(f[0] == 65536 for f in frames[:-1]) and sum(f[0] for f in frames) == n
+    for fcs, blocks in frames:
+        assert len(blocks) == (fcs + 16383) // 16384 and [b[1] for b in blocks] == [0] * (len(blocks) - 1) + [1]
+    print(f"small call {kind} {n}: 16 KiB blocks {len(comp)} vs single-block frames {len(single)} = {len(comp) / len(single):.4f}")
+    assert len(comp) <= len(single) * (1.03 if kind != "runs" else 1.10), (len(comp), len(single))
+    big = datagen.gen("text", (32 << 20) + 65536, 17) if kind == "text" and n == (32 << 20) else None
+    if big is not None:
+        with z.Compressor(1) as c:
+            fr = walk_frames(gpu_lib, c.Wrap(big))
+        assert all(len(b) == 1 for _, b in fr), "above 32 MiB: one block per frame"

@@ -339,6 +339,17 @@ static Framing resolve_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t 
             rs = rf;
         }
     }
+    // Small calls at the fast strategy (64 KiB < size <= kSmallCall, everything left to the level): a call of 10 MiB is 160 chunks on
+    // 256 CUs, and what it waits for is ONE chunk's serial chains — the tANS states of seq_encode and, on the way back, of seq_decode
+    // (~270 ns a sequence, 1.0 of a 2.4 ms round trip), then the Huffman streams.  Frames stay 64 KiB (match execution is ordered per
+    // frame) but are cut into four blocks of 16 KiB, each behind the frame's earlier blocks in LDS (the history form of the dual-hash
+    // levels): same window, four times as many chains a quarter as long, for a block header, a Huffman table and the unknown-repcode
+    // start per 16 KiB (text: + 1.5 % of size).  The finder restages the history per block — on a chip that a call this size leaves idle.
+    constexpr size_t kSmallCall = (size_t)32 << 20;
+    if (!frameBlocks && prefixLen == 0 && chunkBytes == kChunkSize && c->historyBytes < 0 && cp.windowLog == 0 && rs.finder == 0 && rs.minStrideLog == 0 &&
+        paramSize > kChunkSize && paramSize <= kSmallCall) {
+        chunkBytes = 16u << 10; frameBlocks = kChunkSize / chunkBytes;
+    }
     Framing f; f.prefixLen = prefixLen; f.chunkBytes = chunkBytes; f.frameBlocks = frameBlocks; f.rs = rs;
     return f;
 }
