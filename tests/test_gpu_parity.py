@@ -366,8 +366,8 @@ def test_level_finders_sequences_reconstruct_input(gpu_lib, level):
 
 
 def test_levels_buy_ratio(gpu_lib, oracle):
-    """More search effort must not lose ratio (small tolerance: the finders are heuristics), and each tier stays near the
-    reference's own result for that level on the same 64 KiB framing (doubleFast at 3, greedy row-hash at 5)."""
+    """More search effort must not lose ratio (small tolerance: the finders are heuristics), and each tier stays within a stated
+    distance of the reference's own result for that level — at the same framing, and as the reference frames the input (one frame)."""
     sizes = {}
     for kind in ("text", "mixed", "bytei"):
         data = datagen.gen(kind, 1 << 20, 21)
@@ -381,10 +381,23 @@ def test_levels_buy_ratio(gpu_lib, oracle):
         assert sizes[(kind, 7)] <= sizes[(kind, 5)] * 1.005, (kind, sizes)
         if kind == "text":     # level 5 earns its level: the hash-chain search (8 attempts) against the dual-hash finder of level 3
             assert sizes[(kind, 5)] <= sizes[(kind, 3)] * 0.97, (kind, sizes)
-        for level, slack in ((3, 1.035), (5, 1.0)):          # measured (round 2): text 1.0143 / 0.9398, mixed 1.0134 / 0.9758 (+ 2 %; level 5: never above)
-            ref = len(oracle.compress(data, level, 0, 65536))
-            print(f"ratio-vs-oracle L{level} {kind}: gpu {sizes[(kind, level)]} ref {ref} = {sizes[(kind, level)] / ref:.4f}")
-            assert sizes[(kind, level)] <= ref * slack + 64, (kind, level, sizes[(kind, level)], ref)
+        # Against the reference's own parse (the oracle), at EQUAL framing — the level's frame span as independent frames: 240 KiB
+        # (five 48 KiB blocks) at level 3, 256 KiB at level 5; inside a frame the oracle matches across the whole frame, the GPU
+        # finders across 16 / 32 KiB of history plus the block (slack = measured + 2 %) —
+        # and against what the reference really emits for this input, ONE frame with the level's full window (U/Clevels.cs:22, 62:
+        # 512 KiB at level 1, 2 MiB at level 5): that gap is the window the LDS-resident finders do not have
+        for level, span, slack, slack1 in ((3, 5 * (48 << 10), 1.10, 1.20), (5, 256 << 10, 1.085, 1.135)):   # round 3, 1 MiB of text: 1.081 / 1.180 and 1.064 / 1.112 (+ 2 %)
+            ref = len(oracle.compress(data, level, 0, span))
+            one = len(oracle.compress(data, level, 0, 0))
+            print(f"ratio-vs-oracle L{level} {kind}: gpu {sizes[(kind, level)]} oracle at {span >> 10} KiB frames {ref} = {sizes[(kind, level)] / ref:.4f}, "
+                  f"oracle one frame {one} = {sizes[(kind, level)] / one:.4f}")
+            if kind != "bytei":      # (bytei: a 256-byte period — every finder collapses it to a few hundred bytes, ratios of tiny numbers)
+                assert sizes[(kind, level)] <= ref * slack + 64, (kind, level, sizes[(kind, level)], ref)
+                assert sizes[(kind, level)] <= one * slack1 + 64, (kind, level, sizes[(kind, level)], one)
+        if kind != "bytei":
+            one1 = len(oracle.compress(data, 1, 0, 0))
+            print(f"ratio-vs-oracle L1 {kind}: gpu {sizes[(kind, 1)]} oracle one frame {one1} = {sizes[(kind, 1)] / one1:.4f}")
+            assert sizes[(kind, 1)] <= one1 * 1.105 + 64, (kind, sizes[(kind, 1)], one1)
     print("level sizes", sizes)
 
 
