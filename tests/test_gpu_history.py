@@ -240,18 +240,26 @@ def test_levels_above_2_fall_back_to_level_1_where_a_match_finder_finds_nothing(
 
 
 def test_a_long_stretch_without_matches_inside_a_call_is_compressed_as_level_1_would(gpu_lib, oracle):
-    """The sampling works per group of 16 frames; a stretch of 64 MiB or more without matches becomes a range of its own (level 1's
-    finder and framing), the rest keeps the level: the output is the concatenation of what the two parts give on their own.
-    Shorter stretches stay with their surroundings (a range is a pass, and a pass wants thousands of chunks)."""
+    """The sampling works per group of 16 frames; a stretch of 8 MiB or more without matches becomes a range of its own (level 1's
+    finder and framing), the rest keeps the level: the output is the concatenation of what the parts give on their own — also when
+    the kinds alternate (the ranges of a kind are compressed together and their pieces put back in the input's order).
+    Shorter stretches stay with their surroundings."""
     sparse = datagen.gen("zipf", 72 << 20, 5)
     dense = datagen.gen("text", 8 << 20, 6)
     with z.Compressor(5) as c5, z.Compressor(1) as c1:
         whole = c5.Wrap(sparse + dense)
         assert whole == c1.Wrap(sparse) + c5.Wrap(dense)
         assert oracle.decompress(whole, len(sparse) + len(dense)) == sparse + dense
-        short = datagen.gen("zipf", 8 << 20, 5) + dense                # 8 MiB of it: one range, the level's own path throughout
+        # alternating kinds, pieces of 40 MiB (parameters are resolved for the call's size: every piece above the 32 MiB of small calls)
+        a, b, c2, d2 = sparse[:40 << 20], datagen.gen("text", 40 << 20, 7), datagen.gen("rand", 40 << 20, 8), datagen.gen("text", (40 << 20) + 12345, 9)
+        mixed = a + b + c2 + d2
+        out = c5.Wrap(mixed)
+        assert out == c1.Wrap(a) + c5.Wrap(b) + c1.Wrap(c2) + c5.Wrap(d2)
+        with z.Decompressor() as d:
+            assert d.Unwrap(out) == mixed
+        short = datagen.gen("zipf", 4 << 20, 5) + dense                # 4 MiB of it: one range, the level's own path throughout
         out = c5.Wrap(short)
-        assert out != c1.Wrap(short[:8 << 20]) + c5.Wrap(dense)
+        assert out != c1.Wrap(short[:4 << 20]) + c5.Wrap(dense)
         assert walk_frames(gpu_lib, out)[0][0] == (256 << 10) and len(walk_frames(gpu_lib, out)[0][1]) == 8
 
 

@@ -159,6 +159,7 @@ struct ZSTD_CCtx_s {
     // ZSTDMI_CCtx_setDevices: one worker context per listed device (its own stream and workspaces there); a call's frames are
     // dealt to them in contiguous shares (compress_multi).  Empty = the context's own device only.
     std::vector<ZSTD_CCtx_s*> workers;
+    DevBuf gatherIn, gatherOut;     // a many-range plan: the ranges of a kind side by side, and their output (compress_plan)
 };
 // History per chunk lives in LDS beside the chunk: up to 32 KiB of dictionary in front of 32 KiB chunks, or up to 60 KiB when
 // the whole input fits behind it in one chunk (small records, the usual dictionary case).
@@ -357,7 +358,9 @@ static Framing resolve_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t 
 // the compress pipeline over device-resident buffers: one range of the input with one set of parameters (see compress_device)
 // paramSize: the size the parameters are resolved for — the whole range's, of which [d_src, d_src + srcSize) may be a frame-aligned
 // part (a device worker's share of the range, compress_multi): what is written for a stretch of frames depends on nothing else
-static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize, size_t paramSize, bool& first)
+// markAt / marks (optional): input offsets (multiples of the frame span, ascending) whose place in the output is wanted -> marks[i]
+static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize, size_t paramSize, bool& first,
+                             const std::vector<size_t>* markAt = nullptr, std::vector<u64>* marks = nullptr)
 {
     hipStream_t s = c->stream;
     if (srcSize == 0) {     // ZSTD_writeEpilogue on an empty frame: header (FCS=0, single segment) + empty raw last block
@@ -416,7 +419,12 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
         launch_gather(src, n, slots, meta, offsets, d_dst + produced, room, nChunks, chunkBytes, s);      c->timer.mark("gather", s);
         u64 passTotal = 0;
         if (hipMemcpyAsync(&passTotal, total, sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        if (markAt) for (size_t i = 0; i < markAt->size(); ++i) {           // output offsets of the chunks that start at the marked inputs
+            const u64 ck = (*markAt)[i] / chunkBytes;
+            if (ck >= c0 && ck < c0 + nChunks && hipMemcpyAsync(&(*marks)[i], offsets + (ck - c0), sizeof(u64), hipMemcpyDeviceToHost, s) != hipSuccess) return ZERR(kErrGeneric);
+        }
         if (hipStreamSynchronize(s) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+        if (markAt) for (size_t i = 0; i < markAt->size(); ++i) { const u64 ck = (*markAt)[i] / chunkBytes; if (ck >= c0 && ck < c0 + nChunks) (*marks)[i] += produced; }
         // stage times of the call = sums over its passes (inputs above 1 GiB take several)
         c->timer.finish(); c->nStages = c->timer.n;
         for (int i = 0; i < c->timer.n; i++) { c->stageMs[i] = (first ? 0.f : c->stageMs[i]) + c->timer.ms[i]; c->stageNames[i] = c->timer.names[i]; }
@@ -434,10 +442,11 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
 // of the match finder's time.  So a call of 4 MiB or more that leaves strategy, window and history to the level is first looked at
 // in groups of 16 frames (~4 MiB): lz_probe_kernel counts, in eight 4 KiB tiles per group, the positions that repeat an earlier one of
 // their tile or of the 60 KiB in front of it (text: several hundred per tile; Zipf bytes: a handful; an eighth of the input is read).
-// Runs of groups below 32 per tile — the whole call, or at least 64 MiB of it — are compressed as level 1 would (its finder,
+// Runs of groups below 32 per tile — the whole call, or at least 8 MiB of it — are compressed as level 1 would (its finder,
 // independent 64 KiB frames: the same bytes level 1 writes for them), the rest by the level's own path; a group boundary is a frame
 // boundary of both.  The decision is a function of the data alone: probe (device, per group) -> plan (host) -> ranges.
 constexpr u32 kProbeTiles = 8;
+constexpr size_t kMinRunBytes = (size_t)8 << 20;     // a stretch without matches becomes a range of its own from this length on
 struct PlanRange { size_t off, len; bool sparse; };
 
 // does the call get probed, and in groups of how many bytes?  (0 = no probe: one range, the call's own parameters)
@@ -465,12 +474,12 @@ static size_t probe_run(ZSTD_CCtx* c, const u8* d_src, size_t len, size_t front,
 static void plan_ranges(const std::vector<u32>& counts, size_t group, size_t srcSize, std::vector<PlanRange>& out)
 {
     const u32 nGroups = (u32)counts.size();
-    // a range is a pass of its own, and a pass needs thousands of chunks to fill the chip (the entropy stage walks serial chains per
-    // chunk): a stretch without matches counts only if it is the whole call or at least 64 MiB long — measured on the mixed bench
-    // input, whose 6.4 MiB pieces as ranges of their own took 1.7 x the time of one pass over everything
+    // a range is a pass of its own: a stretch without matches counts if it is the whole call or at least kMinRunBytes long (round 2
+    // asked for 64 MiB, because the passes of a many-range plan ran one after the other and none filled the chip: the mixed bench
+    // input's 12.8 MiB pieces took 1.7 x the time as ranges of their own; now the ranges of a kind are compressed as one pass, compress_plan)
     std::vector<u8> sp(nGroups);
     for (u32 g = 0; g < nGroups; ++g) sp[g] = counts[g] < kProbeTiles * 32;
-    const u32 minRun = (u32)(((size_t)64 << 20) / group);
+    const u32 minRun = (u32)((kMinRunBytes + group - 1) / group);
     for (u32 g = 0; g < nGroups; ) {
         u32 e = g + 1;
         while (e < nGroups && sp[e] == sp[g]) ++e;
@@ -496,28 +505,6 @@ static size_t check_call_params(const CallParams& cp)
     return 0;
 }
 
-static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
-{
-    bool first = true;
-    { const size_t e = check_call_params(cp); if (isErr(e)) return e; }
-    size_t err = 0;
-    const size_t group = probe_group_bytes(c, cp, srcSize, err);
-    if (isErr(err)) return err;
-    if (!group) return compress_range(c, cp, d_dst, dstCapacity, d_src, srcSize, srcSize, first);
-    std::vector<u32> counts((srcSize + group - 1) / group);
-    { const size_t e = probe_run(c, d_src, srcSize, 0, group, counts.data()); if (isErr(e)) return e; }
-    std::vector<PlanRange> plan;
-    plan_ranges(counts, group, srcSize, plan);
-    CallParams cpSparse = cp; cpSparse.level = 1;
-    size_t produced = 0;
-    for (const PlanRange& r : plan) {
-        const size_t n = compress_range(c, r.sparse ? cpSparse : cp, d_dst + produced, dstCapacity > produced ? dstCapacity - produced : 0, d_src + r.off, r.len, r.len, first);
-        if (isErr(n)) return n;
-        produced += n;
-    }
-    return produced;
-}
-
 // run f(0 .. n - 1), one host thread each (f(0) on the caller's): a device worker's calls block on its own stream
 // (nothing may leave a thread as an exception: -> false, and the caller reports memory_allocation)
 template <class F> static bool run_on_workers(size_t n, F f)
@@ -535,6 +522,76 @@ template <class F> static bool run_on_workers(size_t n, F f)
 }
 static size_t compress_multi(ZSTD_CCtx* c, const CallParams& cp, void* dst, size_t dstCapacity, const void* src, size_t srcSize);
 
+// A plan of several ranges (a mixed input: stretches the level's finder is for, stretches without matches) as it stands is a run of
+// small passes — a handful of kernels over a few hundred chunks each, none of which fills the chip; side by side on several
+// streams they only queue for the CUs (the finders hold a CU's LDS alone; measured: slower than one after the other).  So the
+// ranges of a KIND are gathered into one contiguous buffer and compressed as ONE pass sequence per kind (range lengths are whole
+// probe groups, i.e. whole frames of either framing; the call's tail is the last range of its kind), each range's place in that
+// output is read back with the pass (marks), and the pieces are copied into the caller's buffer in the order of the input.  Two
+// pass sequences instead of one per range; the bytes are those of the ranges one after the other.  paramSize: the whole call's.
+static size_t compress_plan(ZSTD_CCtx* c, const CallParams& cp, const std::vector<PlanRange>& plan, size_t paramSize, u8* d_dst, size_t dstCapacity, const u8* d_src, bool& first)
+{
+    const size_t R = plan.size();
+    CallParams cpSparse = cp; cpSparse.level = 1;
+    size_t len[2] = {0, 0}, cnt[2] = {0, 0};
+    for (const PlanRange& r : plan) { len[r.sparse] += r.len; cnt[r.sparse]++; }
+    // the kinds' inputs, contiguous (a kind with one range is read where it lies)
+    size_t inAt[2] = {0, len[0] + 256};
+    const size_t inNeed = (cnt[0] > 1 ? len[0] + 256 : 0) + (cnt[1] > 1 ? len[1] + 256 : 0);
+    if (inNeed && !c->gatherIn.ensure(inAt[1] + len[1] + 256)) return ZERR(kErrMemoryAllocation);
+    size_t bound[2], outAt[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) bound[k] = len[k] ? ((ZSTD_compressBound(len[k]) + (len[k] >> 12) + 4096) & ~(size_t)255) : 0;
+    outAt[1] = bound[0];
+    if (!c->gatherOut.ensure(bound[0] + bound[1] + 256)) return ZERR(kErrMemoryAllocation);
+    std::vector<size_t> markAt[2]; std::vector<u64> marks[2];
+    { size_t fill[2] = {0, 0};
+      for (const PlanRange& r : plan) {
+          const int k = r.sparse;
+          markAt[k].push_back(fill[k]);
+          if (cnt[k] > 1 && hipMemcpyAsync((u8*)c->gatherIn.p + inAt[k] + fill[k], d_src + r.off, r.len, hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return ZERR(kErrGeneric);
+          fill[k] += r.len;
+      } }
+    size_t got[2] = {0, 0};
+    for (int k = 0; k < 2; ++k) {
+        if (!len[k]) continue;
+        marks[k].assign(markAt[k].size(), 0);
+        const u8* in = (const u8*)c->gatherIn.p + inAt[k];
+        if (cnt[k] == 1) for (const PlanRange& r : plan) if ((int)r.sparse == k) in = d_src + r.off;
+        const size_t n = compress_range(c, k ? cpSparse : cp, (u8*)c->gatherOut.p + outAt[k], bound[k], in, len[k], paramSize, first, &markAt[k], &marks[k]);
+        if (isErr(n)) return n;
+        got[k] = n;
+    }
+    if (got[0] + got[1] > dstCapacity) return ZERR(kErrDstSizeTooSmall);
+    size_t pos = 0, seen[2] = {0, 0};
+    for (size_t r = 0; r < R; ++r) {
+        const int k = plan[r].sparse;
+        const size_t i = seen[k]++;
+        const u64 lo = marks[k][i], hi = i + 1 < marks[k].size() ? marks[k][i + 1] : got[k];
+        if (hipMemcpyAsync(d_dst + pos, (const u8*)c->gatherOut.p + outAt[k] + lo, (size_t)(hi - lo), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return ZERR(kErrGeneric);
+        pos += (size_t)(hi - lo);
+    }
+    if (hipStreamSynchronize(c->stream) != hipSuccess) { (void)hipGetLastError(); return ZERR(kErrGeneric); }
+    c->lastChunks = 0;
+    return pos;
+}
+
+static size_t compress_device(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size_t dstCapacity, const u8* d_src, size_t srcSize)
+{
+    bool first = true;
+    { const size_t e = check_call_params(cp); if (isErr(e)) return e; }
+    size_t err = 0;
+    const size_t group = probe_group_bytes(c, cp, srcSize, err);
+    if (isErr(err)) return err;
+    if (!group) return compress_range(c, cp, d_dst, dstCapacity, d_src, srcSize, srcSize, first);
+    std::vector<u32> counts((srcSize + group - 1) / group);
+    { const size_t e = probe_run(c, d_src, srcSize, 0, group, counts.data()); if (isErr(e)) return e; }
+    std::vector<PlanRange> plan;
+    plan_ranges(counts, group, srcSize, plan);
+    if (plan.size() == 1) { CallParams one = cp; if (plan[0].sparse) one.level = 1; return compress_range(c, one, d_dst, dstCapacity, d_src, srcSize, srcSize, first); }
+    return compress_plan(c, cp, plan, srcSize, d_dst, dstCapacity, d_src, first);
+}
+
+
 // ======================================================================================================
 extern "C" {
 
@@ -549,7 +606,7 @@ size_t ZSTD_freeCCtx(ZSTD_CCtx* c)
         (void)hipSetDevice(c->device);
         if (c->ownStream) (void)hipStreamSynchronize(c->ownStream);
         c->seqs.release(); c->lits.release(); c->meta.release(); c->tables.release(); c->slots.release(); c->cand.release(); c->probe.release();
-        c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release(); c->dictFullDev.release(); c->dictInfoDev.release();
+        c->gatherIn.release(); c->gatherOut.release(); c->offsets.release(); c->total.release(); c->stageSrc.release(); c->stageDst.release(); c->dict.release(); c->dictFullDev.release(); c->dictInfoDev.release();
         c->timer.destroy();
         if (c->ownStream) (void)hipStreamDestroy(c->ownStream);
     }
@@ -1134,20 +1191,24 @@ static size_t compress_multi(ZSTD_CCtx* c, const CallParams& cp, void* dst, size
     if (group) plan_ranges(counts, group, srcSize, plan);
     else { PlanRange r; r.off = 0; r.len = srcSize; r.sparse = false; plan.push_back(r); }
     CallParams cpSparse = cp; cpSparse.level = 1;
-    // phase B: every worker compresses what the plan's ranges hold of its share
+    // phase B: every worker compresses what the plan's ranges hold of its share (parameters resolved for the whole call, as one device does)
     std::vector<size_t> produced(W, 0);
     ok = run_on_workers(W, [&](size_t i) {
         ZSTD_CCtx* w = c->workers[i];
         if (isErr(cctx_bind(w))) return;
         bool first = true;
+        std::vector<PlanRange> part;
         for (const PlanRange& r : plan) {
             const size_t a = r.off > lo[i] ? r.off : lo[i], b = (r.off + r.len) < lo[i + 1] ? (r.off + r.len) : lo[i + 1];
-            if (a >= b) continue;
-            const size_t n = compress_range(w, r.sparse ? cpSparse : cp, (u8*)w->stageDst.p + produced[i], w->stageDst.cap - produced[i],
-                                            (const u8*)w->stageSrc.p + front[i] + (a - lo[i]), b - a, r.len, first);
-            if (isErr(n)) { res[i] = n; return; }
-            produced[i] += n;
+            if (a < b) { PlanRange q; q.off = a - lo[i]; q.len = b - a; q.sparse = r.sparse; part.push_back(q); }
         }
+        if (part.empty()) return;
+        const u8* base = (const u8*)w->stageSrc.p + front[i];
+        size_t n;
+        if (part.size() == 1) n = compress_range(w, part[0].sparse ? cpSparse : cp, (u8*)w->stageDst.p, w->stageDst.cap, base + part[0].off, part[0].len, srcSize, first);
+        else n = compress_plan(w, cp, part, srcSize, (u8*)w->stageDst.p, w->stageDst.cap, base, first);
+        if (isErr(n)) { res[i] = n; return; }
+        produced[i] = n;
     });
     if (!ok) return ZERR(kErrMemoryAllocation);
     for (size_t i = 0; i < W; ++i) if (isErr(res[i])) return res[i];
