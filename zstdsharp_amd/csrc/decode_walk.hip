@@ -310,6 +310,50 @@ __global__ __launch_bounds__(256) void block_parse_kernel(const u8* __restrict__
 // ------------------------------------------------------------------------------------------------
 // block_link: table provenance inside a frame, literal offsets; one wave per frame, 64 blocks at a time
 // ------------------------------------------------------------------------------------------------
+// frames of up to kLinkSmall blocks (a stream of single-block 64 KiB frames has 16 384 of them per GiB): one LANE per frame, the
+// blocks one after the other — a wave per frame costs three times as much there; longer frames: block_link_kernel below
+constexpr u32 kLinkSmall = 4;
+__global__ __launch_bounds__(64) void block_link_small_kernel(FrameDesc* __restrict__ frames, BlockDesc* __restrict__ blocks, u32 nFrames, u32 haveDict,
+                                                              u32 earlyLiterals, u32* __restrict__ status)
+{
+    const u32 f = blockIdx.x * 64 + threadIdx.x;
+    if (f >= nFrames) return;
+    FrameDesc& F = frames[f];
+    if (F.nbBlocks > kLinkSmall) return;                       // (a wave of block_link_kernel takes it)
+    // a formatted dictionary: every frame starts from its Huffman table and its three FSE tables (ZSTD_decompressBegin_usingDict,
+    // U/ZstdDecompress.cs:1956-1990); without one nothing is defined before the frame's first block defines it
+    u32 lastHuf = haveDict ? kDictBlock : kNoBlock;
+    u32 lastTbl[3] = { lastHuf, lastHuf, lastHuf };
+    u64 litAcc = 0; u32 hasSeq = 0;
+    for (u32 k = 0; k < F.nbBlocks; ++k) {
+        const u32 bi = F.firstBlock + k;
+        BlockDesc& B = blocks[bi];
+        if (B.type != 2 || B.err) continue;
+        u32 err = 0;
+        if (B.litType == 2) { lastHuf = bi; B.hufSrc = bi; }
+        else if (B.litType == 3) { B.hufSrc = lastHuf; if (lastHuf == kNoBlock) err = kErrDictionaryCorrupted; }     // U/ZstdDecompressBlock.cs:197-207
+        if (B.litType >= 2) {
+            if (B.litSize > F.dstSize - litAcc) { err = err ? err : (u32)kErrCorruption; B.litRel = 0; }
+            else { B.litRel = litAcc; litAcc += B.litSize; }
+            B.litInPlace = (B.nbSeq == 0 && (!earlyLiterals || (k == 0 && !F.unsized))) ? 1u : 0u;
+        }
+        if (B.nbSeq) {
+            hasSeq = 1;
+#pragma unroll
+            for (u32 t = 0; t < 3; ++t) {
+                const u32 mode = (B.modes >> (6 - 2 * t)) & 3;
+                if (mode == 3) { B.tblSrc[t] = lastTbl[t]; if (lastTbl[t] == kNoBlock) err = err ? err : (u32)kErrCorruption; }   // :1780-1786
+                else { B.tblSrc[t] = bi; lastTbl[t] = bi; }
+            }
+        }
+        if (err) { B.err = err; report_error(status, bi, B.litType >= 2 && (err == kErrDictionaryCorrupted || B.litSize > F.dstSize) ? kStageLiterals : kStageSequences, err); }
+    }
+    F.hasSeq = hasSeq;
+    if (litAcc) atomicAdd(reinterpret_cast<unsigned long long*>(status + kStLitLo), (unsigned long long)litAcc);
+    if (hasSeq && F.dstSize >= (1u << 20) && F.dstSize < (1ull << 30))
+        atomicAdd(reinterpret_cast<unsigned long long*>(status + kStBigBins) + highbit32((u32)(F.dstSize >> 20)), (unsigned long long)F.dstSize);
+}
+
 // "the latest earlier block that ..." over the 64 blocks of a batch: the highest lane below mine in `mask`, else what earlier batches left
 __device__ __forceinline__ u32 latest_before(u64 mask, u32 firstOfBatch, u32 carried, u32 lane)
 {
@@ -323,6 +367,7 @@ __global__ __launch_bounds__(64) void block_link_kernel(FrameDesc* __restrict__ 
     if (f >= nFrames) return;
     FrameDesc& F = frames[f];
     const u32 first = uniform(F.firstBlock), nb = uniform(F.nbBlocks);
+    if (nb <= kLinkSmall) return;                              // (a lane of block_link_small_kernel takes it)
     const u64 dstSize = F.dstSize;
     // a formatted dictionary: every frame starts from its Huffman table and its three FSE tables (ZSTD_decompressBegin_usingDict,
     // U/ZstdDecompress.cs:1956-1990); without one nothing is defined before the frame's first block defines it
@@ -418,7 +463,8 @@ __global__ __launch_bounds__(1024) void seq_scan_kernel(BlockDesc* __restrict__ 
 void launch_block_prepass(const u8* src, FrameDesc* frames, BlockDesc* blocks, u32 nFrames, u32 nBlocks, u32 haveDict, u32 earlyLiterals, u32* status, hipStream_t stream)
 {
     hipLaunchKernelGGL(block_parse_kernel, dim3((nBlocks + 255) / 256), dim3(256), 0, stream, src, blocks, nBlocks, status);
-    hipLaunchKernelGGL(block_link_kernel, dim3(nFrames), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, earlyLiterals, status);
+    hipLaunchKernelGGL(block_link_small_kernel, dim3((nFrames + 63) / 64), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, earlyLiterals, status);
+    if (nBlocks > nFrames) hipLaunchKernelGGL(block_link_kernel, dim3(nFrames), dim3(64), 0, stream, frames, blocks, nFrames, haveDict, earlyLiterals, status);      // (some frame has several blocks)
     hipLaunchKernelGGL(seq_scan_kernel, dim3(1), dim3(1024), 0, stream, blocks, nBlocks, status);
 }
 
