@@ -637,3 +637,28 @@ def test_output_is_deterministic_on_sparse_and_dense_data_at_size(gpu_lib):
                         ref = (cs, dst[:cs].clone())
                     else:
                         assert cs == ref[0] and bool(torch.equal(dst[:cs], ref[1])), (kind, level)
+
+
+def test_rle_and_raw_blocks_above_the_block_size_limit_follow_the_reference(gpu_lib, oracle):
+    """A block header's size field is 21 bits wide; the reference's one-shot decoder checks a COMPRESSED block against the 128 KiB
+    limit (U/ZstdDecompressBlock.cs:3095-3098) but takes an RLE or raw block's size as it stands (ZSTD_setRleBlock / ZSTD_copyRawBlock,
+    U/ZstdDecompress.cs:1004-1052; only the streaming decoder refuses, :2965+).  Hand-made frames; whatever the oracle does, the GPU does."""
+    def frame(blocks, n):
+        out = bytes([0x28, 0xB5, 0x2F, 0xFD, 0xA0]) + n.to_bytes(4, "little")          # single segment, 4-byte content size
+        for i, (btype, size, payload) in enumerate(blocks):
+            hdr = (1 if i == len(blocks) - 1 else 0) | (btype << 1) | (size << 3)
+            out += hdr.to_bytes(3, "little") + payload
+        return out
+    raw = datagen.gen("text", 150000, 5)
+    cases = [frame([(1, 200000, b"\x5a")], 200000),                                        # one RLE block of 200 000 bytes
+             frame([(0, 150000, raw)], 150000),                                              # one raw block of 150 000 bytes
+             frame([(1, 131072, b"a"), (1, 300000, b"b"), (0, 10, b"0123456789")], 131072 + 300000 + 10),
+             frame([(1, 200000, b"\x5a")], 199999)]                                          # content size and blocks disagree
+    with z.Decompressor() as d:
+        for blob in cases:
+            want = oracle.decompress(blob, 1 << 20)
+            try:
+                got = d.Unwrap(blob)
+            except z.ZstdException as e:
+                got = -int(e.Code)
+            assert got == want or (isinstance(want, int) and isinstance(got, int)), (len(blob), want if isinstance(want, int) else len(want), got if isinstance(got, int) else len(got))

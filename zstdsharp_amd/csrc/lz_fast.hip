@@ -784,7 +784,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocks, u16* __restrict__ candAll, u16* __restrict__ chainAll, u32* __restrict__ regionList, const u32 nChunks)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocksArg, u16* __restrict__ candAll, u16* __restrict__ chainAll, u32* __restrict__ regionList, const u32 nChunks)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
@@ -807,10 +807,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     const u32 hist = DICT ? kChunkSize - ((chunkBytes + kTilePos - 1) & ~(kTilePos - 1)) : 0u;      // (chunks below a tile: ZSTD_c_windowLog 10, 11)
     const u64 base = (u64)c * cb;
     const u8* __restrict__ in = src + base;
+    // (frameBlocksArg bit 31: the frame's blocks are independent of each other — windows below 64 KiB, where a block IS the window:
+    //  no history; a dictionary is history of the frame's first block only, whose image is the layout the decoder sees)
+    const u32 frameBlocks = frameBlocksArg & 0x7FFFFFFFu;
+    const bool indep = (frameBlocksArg >> 31) != 0;
     const u32 bf = ((DICT || FAR) && frameBlocks) ? c % frameBlocks : 0u;               // block index inside its frame
     const u32 farAvail = FAR ? ((u64)bf * cb < kFarMax ? bf * cb : kFarMax) : 0u;      // bytes of far history in front of the block
     u32 prefixLen = prefixLenArg; const u8* __restrict__ prefix = prefixArg;
-    if (DICT && frameBlocks) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
+    if (DICT && frameBlocks && !indep) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
+    if (DICT && indep && bf) prefixLen = 0;
     const u32 lowLimit = DICT ? hist - prefixLen : 0u;
     const u32 nData = (u32)((srcSize - base) < cb ? (srcSize - base) : cb);
     const u32 n = hist + nData;                            // end of the data in LDS
@@ -819,7 +824,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 #endif
 
     // ---- stage the chunk: 16 B per lane when the source is 16-byte aligned ----
-    if (DICT && frameBlocks && ((((uintptr_t)prefix) | lowLimit) & 15) == 0) {
+    if (DICT && frameBlocks && !indep && ((((uintptr_t)prefix) | lowLimit) & 15) == 0) {
         // cross-chunk history: the history and the block are ONE contiguous piece of the input (at most 64 KiB): four 16-byte
         // pieces per thread, all loads in flight before the first store (pieces past the end re-read piece 0 and are not stored)
         const uint4* in4 = reinterpret_cast<const uint4*>(prefix);
@@ -1463,8 +1468,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         if ((DICT || FAR) && frameBlocks) {   // only a frame's first block carries the frame header, sized for the whole frame's content
             const u64 fStart = base - (u64)bf * cb, fMax = (u64)frameBlocks * cb;
             const u64 fLen = (srcSize - fStart) < fMax ? (srcSize - fStart) : fMax;
-            m.fhSize = bf == 0 ? ((fhExtra >> 8) ? 6u : frame_header_size64(fLen)) + (fhExtra & 7u) : 0u;
-        } else m.fhSize = ((fhExtra >> 8) ? 6u : frame_header_size(nData)) + (fhExtra & 7u);      // fhExtra: bytes of the dictID field (formatted dictionary), else 0; bit 8: window descriptor instead of a content size (magic, descriptor, window byte)
+            const u32 fcsField = fLen < 256 ? 0u : fLen < 65536 + 256 ? 2u : fLen <= 0xFFFFFFFFull ? 4u : 8u;       // (behind a window descriptor)
+            m.fhSize = bf == 0 ? ((fhExtra >> 12) ? 6u + ((fhExtra & 0x100u) ? 0u : fcsField) : (fhExtra & 0x100u) ? 6u : frame_header_size64(fLen)) + (fhExtra & 7u) : 0u;
+        } else m.fhSize = ((fhExtra & 0x100u) ? 6u : frame_header_size(nData)) + (fhExtra & 7u);      // fhExtra: bits 0-2 bytes of the dictID field (formatted dictionary); bit 8: window descriptor instead of a content size (magic, descriptor, window byte); bits 12-16: an explicit windowLog (multi-block frames only: descriptor AND content size)
         m.litFromSrc = deferred ? 1u : 0u;       // (then nbSeq = 0 and litBase = nData: the literals are the chunk itself)
         m.regionCursor = regionCursor;
         meta[c] = m;
@@ -1483,8 +1489,10 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
 template <int MODE, bool DICT>
 __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ src, u64 srcSize, Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                          ChunkMeta* __restrict__ meta, u16* __restrict__ candAll, u16* __restrict__ chainAll, const u32* __restrict__ regionList,
-                                                         const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes, const u32 frameBlocks, const u32 hcDepth)
+                                                         const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes, const u32 frameBlocksArg, const u32 hcDepth)
 {
+    const u32 frameBlocks = frameBlocksArg & 0x7FFFFFFFu;
+    const bool indep = (frameBlocksArg >> 31) != 0;
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
     const u32 tid = threadIdx.x, lane = lane_id(), wave = uniform(wave_id());
@@ -1500,12 +1508,13 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
     const u8* __restrict__ in = src + base;
     const u32 bf = (DICT && frameBlocks) ? c % frameBlocks : 0u;
     u32 prefixLen = prefixLenArg; const u8* __restrict__ prefix = prefixArg;
-    if (DICT && frameBlocks) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
+    if (DICT && frameBlocks && !indep) { const u64 back = (u64)bf * cb; prefixLen = back < hist ? (u32)back : hist; prefix = in - prefixLen; }
+    if (DICT && indep && bf) prefixLen = 0;
     const u32 lowLimit = DICT ? hist - prefixLen : 0u;
     const u32 nData = (u32)((srcSize - base) < cb ? (srcSize - base) : cb);
     const u32 n = hist + nData;
     {   // the image [lowLimit, n): history (or dictionary tail) + block.  Cross-chunk history is one contiguous piece of the input
-        const bool onePiece = !DICT || frameBlocks != 0;
+        const bool onePiece = !DICT || (frameBlocks != 0 && !indep);
         const u8* __restrict__ from = onePiece ? in - prefixLen : in;
         const u32 at = onePiece ? lowLimit : hist, bytes = onePiece ? prefixLen + nData : nData;
         if ((((uintptr_t)from) | at) % 16 == 0) {

@@ -436,11 +436,18 @@ __global__ __launch_bounds__(256) void seq_encode_kernel(Seq* __restrict__ seqs,
     if (bf == 0) {
         writeLE32(slot, 0xFD2FB528u);
         const u32 didCode = dictIdBytes == 4 ? 3u : dictIdBytes;          // dictID field of 0, 1, 2 or 4 bytes (U/ZstdCompress.cs:4843-4849, 4896-4918)
-        if (checksumFlag & 2u) {
-            u32 wl = 10; while (((u64)1 << wl) < frameLen) ++wl;
-            slot[4] = (u8)(didCode + ((checksumFlag & 1u) << 2));
+        const u32 wlSet = (checksumFlag >> 8) & 31u;          // an explicit window (frames of independent blocks, each a window long)
+        if ((checksumFlag & 2u) || wlSet) {
+            u32 wl = wlSet;
+            if (!wl) { wl = 10; while (((u64)1 << wl) < frameLen) ++wl; }
+            const u32 fcsCode = (checksumFlag & 2u) ? 0u : (frameLen >= 256) + (frameLen >= 65536 + 256) + (frameLen > 0xFFFFFFFFull);
+            slot[4] = (u8)(didCode + ((checksumFlag & 1u) << 2) + (fcsCode << 6));
             slot[5] = (u8)((wl - 10) << 3);
             for (u32 i = 0; i < dictIdBytes; i++) slot[6 + i] = (u8)(dictID >> (8 * i));
+            u8* const fcs = slot + 6 + dictIdBytes;               // (not a single segment: a content size below 256 has no field)
+            if (fcsCode == 1) writeLE16(fcs, (u32)frameLen - 256);
+            else if (fcsCode == 2) writeLE32(fcs, (u32)frameLen);
+            else if (fcsCode == 3) { writeLE32(fcs, (u32)frameLen); writeLE32(fcs + 4, (u32)(frameLen >> 32)); }
         } else {
             const u32 fcsCode = (frameLen >= 256) + (frameLen >= 65536 + 256) + (frameLen > 0xFFFFFFFFull);
             slot[4] = (u8)(didCode + ((checksumFlag & 1u) << 2) + (1u << 5) + (fcsCode << 6));

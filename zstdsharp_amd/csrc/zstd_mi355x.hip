@@ -307,14 +307,15 @@ static size_t cctx_sync_dictionary(ZSTD_CCtx* c)
 // How a range of paramSize bytes is cut into blocks and frames (a function of the parameters, the loaded dictionary and that size):
 // bytes of dictionary in front of every chunk, bytes per block, blocks per frame (0 = every block a frame of its own), and what
 // the level resolves to for it.
-struct Framing { u32 prefixLen, chunkBytes, frameBlocks; Resolved rs; size_t span() const { return (size_t)chunkBytes * (frameBlocks ? frameBlocks : 1u); } };
+struct Framing { u32 prefixLen, chunkBytes, frameBlocks; Resolved rs; u32 indepWindowLog = 0; size_t span() const { return (size_t)chunkBytes * (frameBlocks ? frameBlocks : 1u); } };
 static Framing resolve_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t paramSize)
 {
     const u32 prefixLen = cp.useDict ? dict_prefix_len(c, paramSize) : 0u;
     u32 chunkBytes = kChunkSize - round_tile(prefixLen);
     // ZSTD_c_windowLog 10 .. 15: independent frames of 1 << windowLog bytes (the reference cuts blocks at the window size and lets
     // no offset exceed it, U/ZstdCompress.cs:4690-4712, U/ZstdCompressInternal.cs:787-813; a frame that IS its own window does both)
-    if (cp.windowLog >= 10 && cp.windowLog < (int)kChunkLog && chunkBytes > (1u << cp.windowLog)) chunkBytes = 1u << cp.windowLog;
+    u32 indepWindowLog = 0;
+    if (cp.windowLog >= 10 && cp.windowLog < (int)kChunkLog && chunkBytes > (1u << cp.windowLog)) { chunkBytes = 1u << cp.windowLog; indepWindowLog = (u32)cp.windowLog; }
     Resolved rs = resolve_call(cp, paramSize, chunkBytes);
     // Cross-chunk history (the window the block loop carries, U/ZstdCompress.cs:4705-4807): blocks of 64 KiB - hist
     // bytes, each with the hist bytes in front of it as match-only history in LDS, frameBlocks of them to a frame (so a
@@ -351,7 +352,11 @@ static Framing resolve_framing(const ZSTD_CCtx* c, const CallParams& cp, size_t 
         paramSize > kChunkSize && paramSize <= kSmallCall) {
         chunkBytes = 16u << 10; frameBlocks = kChunkSize / chunkBytes;
     }
-    Framing f; f.prefixLen = prefixLen; f.chunkBytes = chunkBytes; f.frameBlocks = frameBlocks; f.rs = rs;
+    // ZSTD_c_windowLog 10 .. 15 (continued): the blocks of 1 << windowLog bytes are independent of each other but share frames of 64 KiB
+    // with a window descriptor of exactly that windowLog — a frame per block would cost 13 bytes per KiB on incompressible input, more
+    // than ZSTD_compressBound grants (the reference spends a 3-byte block header per window)
+    if (indepWindowLog && paramSize > chunkBytes) frameBlocks = kChunkSize / chunkBytes; else indepWindowLog = 0;
+    Framing f; f.prefixLen = prefixLen; f.chunkBytes = chunkBytes; f.frameBlocks = frameBlocks; f.rs = rs; f.indepWindowLog = indepWindowLog;
     return f;
 }
 
@@ -378,6 +383,8 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
     if (cp.useDict) { const size_t e = cctx_sync_dictionary(c); if (isErr(e)) return e; }
     const Framing fr = resolve_framing(c, cp, paramSize);
     const u32 prefixLen = fr.prefixLen, chunkBytes = fr.chunkBytes, frameBlocks = fr.frameBlocks;
+    const u32 lzFrameBlocks = frameBlocks | (fr.indepWindowLog ? 0x80000000u : 0u);       // (independent blocks: no history between them)
+    const u32 hdrWindow = fr.indepWindowLog;
     const Resolved rs = fr.rs;
     // a formatted dictionary: its dictID in every frame header (unless ZSTD_c_dictIDFlag = 0), its repcodes in front of every frame
     const bool fmtDict = cp.useDict && c->dictFormatted;
@@ -407,11 +414,11 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
         Seq* seqs = (Seq*)c->seqs.p; u8* lits = (u8*)c->lits.p; ChunkMeta* meta = (ChunkMeta*)c->meta.p;
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
-        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes | (cp.contentSizeFlag ? 0u : 0x100u), rs.minStrideLog, frameBlocks, regionParse ? (u16*)c->cand.p : nullptr, hcChains ? (u16*)((u8*)c->cand.p + cand_plane_bytes(passChunks)) : nullptr,
+        launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes | (cp.contentSizeFlag ? 0u : 0x100u) | (hdrWindow << 12), rs.minStrideLog, lzFrameBlocks, regionParse ? (u16*)c->cand.p : nullptr, hcChains ? (u16*)((u8*)c->cand.p + cand_plane_bytes(passChunks)) : nullptr,
                   regionParse ? (u32*)((u8*)c->cand.p + cand_plane_bytes(passChunks) * (hcChains ? 2 : 1)) : nullptr, hcDepth, s, c->timer.hook());
         launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s, c->timer.hook());
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
-        launch_seq_encode(seqs, meta, slots, nChunks, strategy, (cp.checksumFlag ? 1u : 0u) | (cp.contentSizeFlag ? 0u : 2u), 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
+        launch_seq_encode(seqs, meta, slots, nChunks, strategy, (cp.checksumFlag ? 1u : 0u) | (cp.contentSizeFlag ? 0u : 2u) | (hdrWindow << 8), 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
         launch_scan_sizes(meta, nChunks, offsets, total, s);                       c->timer.mark("scan", s);
         const size_t room = dstCapacity > produced ? dstCapacity - produced : 0;
         // the literals section (most of the output) is encoded straight into its final place; gather moves the rest
