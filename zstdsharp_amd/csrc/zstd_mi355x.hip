@@ -1026,7 +1026,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     // blocks neither fills the chip — both are serial chains per block — so below kOverlapBlocks the literal decoder may run beside
     // seq_decode on a stream of its own (`early`: block_link then lets it write only the outputs whose place is known by now).
     // Whether it does is decided once the pre-pass has counted both kinds of work (below).
-    constexpr u32 kOverlapBlocks = 24576;
+    constexpr u32 kOverlapBlocks = 12288;
     const bool early = d->overlapMode == 2 || (d->overlapMode == 0 && nBlocks <= kOverlapBlocks);
     launch_block_prepass(d_src, frames, blocks, nFrames, nBlocks, fmt ? 1u : 0u, early ? 1u : 0u, status, s);
     if (!read_status(st)) return ZERR(kErrGeneric);
