@@ -1062,12 +1062,13 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     }
     SeqRec* recs = (SeqRec*)d->recs.p;
     struct AuxGuard { hipStream_t a; bool on; ~AuxGuard() { if (on) (void)hipStreamSynchronize(a); } } auxGuard{ d->aux, false };   // nothing of this call outlives it
-    // Beside each other only when both are substantial: a Huffman symbol costs its chain about 20 ns per literal byte (four streams),
-    // a sequence about 270 ns — text (three or four literal bytes per sequence) has nothing to hide behind seq_decode and only loses LDS
+    // Beside each other only when both are substantial (from five coded literal bytes per sequence): a Huffman symbol costs its chain
+    // about 26 ns per literal byte (four streams), a sequence about 270 ns — text (three or four literal bytes per sequence) has nothing to hide behind seq_decode and only loses LDS
     // bandwidth to the company (measured: 1 GiB of 1 MiB level-5 frames, mixed corpus 14.7 -> 13.4 ms, text 15.5 -> 15.7 ms), and
     // input without sequences (Zipf bytes) has no seq_decode to hide behind.
     const u64 litBytes = (u64)st[kStLitLo] | ((u64)st[kStLitHi] << 32);
-    const bool beside = early && nSeq && (d->overlapMode == 2 || (litBytes >= 8 * nSeq && nSeq >= 64 * (u64)nBlocks));
+    const bool beside = early && nSeq && (d->overlapMode == 2 || (litBytes >= 5 * nSeq && nSeq >= 64 * (u64)nBlocks));
+    if (getenv("ZMI_DEBUG")) fprintf(stderr, "zmi: blocks %u seqs %llu coded literal bytes %llu early %d beside %d\n", nBlocks, (unsigned long long)nSeq, (unsigned long long)litBytes, (int)early, (int)beside);
     if (beside) {               // (the host has just waited for the pre-pass: everything the literal decoder reads is there)
         launch_decode_literals(d_src, d_dst, (u8*)d->scratch.p, frames, blocks, nBlocks, status, (u8*)d->slowFlags.p, d->litDecoder, dictFull, dinfo, d->aux, StageHook());
         if (hipEventRecord(d->auxDone, d->aux) != hipSuccess) return ZERR(kErrGeneric);
