@@ -229,41 +229,90 @@ __device__ inline u32 huf_set_max_height_wave(LDS& L, Node* huffNode, u32 lastNo
 }
 
 // ---- HUF_compressWeights (U/HufCompress.cs:40-125); returns bytes written, 0 = not compressible, 1 = single symbol ----
-__device__ inline u32 huf_compress_weights(HufTreeLds& L, u8* dst, u32 wtSize)
+// Called by all 64 lanes of the chunk's wave (the result is uniform).  Lane 0 takes the decisions, FSE_normalizeCount and
+// FSE_writeNCount (13 symbols); the table is built by the wave; then FSE_compress_usingCTable_generic (U/FseCompress.cs:722-820):
+// symbol i uses state (i & 1), last symbol first — two independent chains, so lane p walks the symbols of parity p (each lane
+// first fetches the transforms of its four symbols, so a chain step is one dependent LDS read) and leaves (bits, count) per
+// symbol; the fields are placed by a prefix sum over the emission order and OR-ed into an LDS bit buffer, the two final states
+// and the end mark behind them (BIT_closeCStream), and the bytes copied out.  (On one lane with a serial bit writer this was
+// 300 000 cycles per chunk — the longest stretch of huf_tree_kernel; byte-identical by tests/test_gpu_parity.py.)
+// Scratch: the tree's node array, dead by now.
+__device__ inline u32 huf_compress_weights_wave(HufTreeLds& L, u8* dst, u32 wtSize, u32 lane)
 {
-    u32 maxSV = 12;
-    if (wtSize <= 1) return 0;
-    // L.wcount = histogram of the weights, accumulated by the threads that produced them
-    while (!L.wcount[maxSV]) maxSV--;
-    u32 maxCount = 0;
-    for (u32 s = 0; s <= maxSV; s++) if (L.wcount[s] > maxCount) maxCount = L.wcount[s];
-    if (maxCount == wtSize) return 1;
-    if (maxCount == 1) return 0;
-    const u32 tableLog = fse_optimal_table_log(6, wtSize, maxSV, 2);
-    if (!fse_normalize_count(L.wnorm, tableLog, L.wcount, wtSize, maxSV, 0)) return 0;
-    u8* op = dst;
-    const u32 hs = fse_write_ncount(op, L.wnorm, maxSV, tableLog);
-    if (!hs) return 0;
-    op += hs;
-    fse_build_ctable(L.wstate, L.wtt, L.wnorm, maxSV, tableLog, L.wcumul, L.wsym);
-    // FSE_compress_usingCTable_generic (U/FseCompress.cs:722-820): symbol i uses state (i & 1), last symbol first
-    if (wtSize <= 2) return 0;
-    BitW bw; bw.init(op);
-    u32 st0 = 0, st1 = 0;          // (two named states: an indexed pair would live in scratch memory)
-    { const u32 v = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 1]); if ((wtSize - 1) & 1) st1 = v; else st0 = v; }
-    { const u32 v = fse_init_state2(L.wstate, L.wtt, L.weights[wtSize - 2]); if ((wtSize - 2) & 1) st1 = v; else st0 = v; }
-    for (u32 i = wtSize - 2; i-- > 0; ) {
-        const SymTT t = L.wtt[L.weights[i]];
-        u32 v = (i & 1) ? st1 : st0;
-        const u32 nbBitsOut = (v + t.deltaNbBits) >> 16;
-        bw.add(v, nbBitsOut);
-        v = L.wstate[(s32)(v >> nbBitsOut) + t.deltaFindState];
-        if (i & 1) st1 = v; else st0 = v;
+    u32* const fields = reinterpret_cast<u32*>(L.nodes);            // [256] value | nbBits << 16, by symbol index
+    SymTT* const tts = reinterpret_cast<SymTT*>(fields + 256);      // [256] the symbols' transforms
+    u32* const bitbuf = reinterpret_cast<u32*>(tts + 256);          // [64]
+    u16* const cumR = reinterpret_cast<u16*>(bitbuf + 64);          // [64] scratch of the table build
+    static_assert(256 * 4 + 256 * sizeof(SymTT) + 64 * 4 + 64 * 2 <= sizeof(L.nodes), "scratch fits the node array");
+    u32 res = 0xFFFFFFFFu, maxSV = 12, tableLog = 0, hs = 0;
+    if (lane == 0) {
+        do {
+            if (wtSize <= 1) { res = 0; break; }
+            while (!L.wcount[maxSV]) maxSV--;
+            u32 maxCount = 0;
+            for (u32 s = 0; s <= maxSV; s++) if (L.wcount[s] > maxCount) maxCount = L.wcount[s];
+            if (maxCount == wtSize) { res = 1; break; }
+            if (maxCount == 1) { res = 0; break; }
+            tableLog = fse_optimal_table_log(6, wtSize, maxSV, 2);
+            if (!fse_normalize_count(L.wnorm, tableLog, L.wcount, wtSize, maxSV, 0)) { res = 0; break; }
+            hs = fse_write_ncount(dst, L.wnorm, maxSV, tableLog);
+            if (!hs) { res = 0; break; }
+            if (wtSize <= 2) { res = 0; break; }
+        } while (false);
     }
-    bw.add(st1, tableLog);
-    bw.add(st0, tableLog);
-    op = bw.close();
-    return (u32)(op - dst);
+    res = uniform(res); maxSV = uniform(maxSV); tableLog = uniform(tableLog); hs = uniform(hs);
+    if (res != 0xFFFFFFFFu) return res;
+    wave_lds_sync();                                                // (wnorm)
+    fse_build_ctable_wave(L.wstate, L.wtt, L.wnorm, maxSV, tableLog, cumR, L.wsym, lane);
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) { const u32 i = k * 64 + lane; if (i < wtSize) tts[i] = L.wtt[L.weights[i]]; }
+    if (lane < 64) bitbuf[lane] = 0;
+    wave_lds_sync();
+    if (lane < 2) {                                                 // the chain of parity `lane`
+        const int top = (int)(wtSize - 1) - ((((wtSize - 1) & 1u) != lane) ? 1 : 0);
+        u32 v = fse_init_state2(L.wstate, L.wtt, L.weights[top]);
+        for (int i = top - 2; i >= 0; i -= 2) {
+            const SymTT t = tts[i];
+            const u32 nb = (v + t.deltaNbBits) >> 16;
+            fields[i] = (v & ((1u << nb) - 1u)) | (nb << 16);
+            v = L.wstate[(s32)(v >> nb) + t.deltaFindState];
+        }
+        L.sh[6 + lane] = v;                                         // (kShRoot and kShHSize: free by now)
+    }
+    wave_lds_sync();
+    // emission order: symbol wtSize - 3 first, symbol 0 last; rank r = wtSize - 3 - i
+    const u32 nEmit = wtSize - 2;
+    u32 carry = 0;
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) {
+        const u32 r = k * 64 + lane;
+        const bool have = r < nEmit;
+        const u32 f = have ? fields[nEmit - 1 - r] : 0u;
+        const u32 nb = f >> 16, val = f & 0xFFFFu;
+        const u32 incl = wave_scan_incl(nb);
+        const u32 at = carry + incl - nb;
+        if (nb) {
+            const u64 sh = (u64)val << (at & 31u);
+            atomicOr(&bitbuf[at >> 5], (u32)sh);
+            if ((u32)(sh >> 32)) atomicOr(&bitbuf[(at >> 5) + 1], (u32)(sh >> 32));
+        }
+        carry += read_lane(incl, 63);
+    }
+    wave_lds_sync();
+    if (lane == 0) {                                                // FSE_flushCState x2 (state 2 first) + the end mark
+        const u32 st0 = L.sh[6], st1 = L.sh[7], mask = (1u << tableLog) - 1u;
+        const u64 tail = (u64)(st1 & mask) | ((u64)(st0 & mask) << tableLog) | (1ull << (2 * tableLog));
+        const u32 at = carry;
+        const u64 lo = tail << (at & 31u);                          // (2 * 6 + 1 bits shifted by at most 31: fits 64)
+        bitbuf[at >> 5] |= (u32)lo;
+        if ((u32)(lo >> 32)) bitbuf[(at >> 5) + 1] |= (u32)(lo >> 32);
+    }
+    wave_lds_sync();
+    const u32 nBytes = (carry + 2 * tableLog + 1 + 7) >> 3;
+    const u8* const bytes = reinterpret_cast<const u8*>(bitbuf);
+#pragma unroll
+    for (u32 k = 0; k < 4; ++k) { const u32 i = k * 64 + lane; if (i < nBytes) dst[hs + i] = bytes[i]; }
+    return hs + nBytes;
 }
 
 __device__ __forceinline__ u32 min_gain(u32 srcSize) { return (srcSize >> 6) + 2; }   // ZSTD_minGain, strategies < btultra
@@ -512,6 +561,8 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
         wave_lds_sync();
         ZMI_HSTAMP(6);
     }
+    u32 wsWave = 0;
+    if (shCompressed) wsWave = huf_compress_weights_wave(L, T->hdr + 1, maxSV, lane);      // (uniform branch, uniform result)
     if (tid != 0) return;
 
     // ---------------- remaining serial section: tree description + decisions ----------------
@@ -521,7 +572,7 @@ __global__ __launch_bounds__(64) void huf_tree_kernel(ChunkMeta* __restrict__ me
     u32 streamSize[4] = { 0, 0, 0, 0 };
     if (compressed) {
         T->maxSV = maxSV; T->tableLog = huffLog;
-        const u32 ws = huf_compress_weights(L, T->hdr + 1, maxSV);
+        const u32 ws = wsWave;
         if (ws > 1 && ws < maxSV / 2) { T->hdr[0] = (u8)ws; hSize = ws + 1; }
         else if (maxSV > 128) { compressed = false; }     // HUF_writeCTable_wksp fails -> ZSTD_compressLiterals stores raw
         else {

@@ -54,68 +54,6 @@ struct SeqWaveLds {
 
 struct SeqTable { const u16* state; const SymTT* tt; u32 tableLog; };
 
-// FSE_buildCTable_wksp (U/FseCompress.cs:20-160) by the 64 lanes of the chunk's wave; lane s stands for symbol s.  Same
-// restatement as the decoder's table build (decode.hip): low-probability symbols take the top cells in symbol order; the
-// reference's spreading visits (i*step) & mask for i = 0, 1, ... and skips cells above highThreshold, so the j-th cell it
-// keeps belongs to the symbol whose cumulative count covers j; `stateTable[cumul[s]++] = tableSize + u` in cell order is a
-// ballot rank per symbol with the counter kept in that symbol's lane; the per-symbol transforms are independent.
-__device__ __forceinline__ void fse_build_ctable_wave(u16* stateTable, SymTT* tt, const s16* norm, u32 maxSV, u32 tableLog,
-                                                      u16* cumR, u8* tableSymbol, u32 lane)
-{
-    const u32 tableSize = 1u << tableLog, mask = tableSize - 1, step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    const int nc = lane <= maxSV ? (int)norm[lane] : 0;
-    const bool low = nc == -1;
-    const u64 lowMask = ballot(low);
-    const u32 highThreshold = tableSize - 1 - popc64(lowMask);
-    if (low) tableSymbol[tableSize - 1 - popc64(lowMask & lanemask_lt())] = (u8)lane;
-    const u32 cntAll = low ? 1u : (nc > 0 ? (u32)nc : 0u), cntReg = nc > 0 ? (u32)nc : 0u;
-    const u32 inclAll = wave_scan_incl(cntAll), inclReg = wave_scan_incl(cntReg);
-    const u32 total = inclAll - cntAll;                    // cumul[s]: first state-table slot of symbol s
-    cumR[lane] = (u16)(inclReg - cntReg);
-    wave_lds_sync();
-    u32 jBase = 0;
-    for (u32 i0 = 0; i0 < tableSize; i0 += 64) {
-        const u32 i = i0 + lane, p = (i * step) & mask;
-        const bool place = i < tableSize && p <= highThreshold;
-        const u64 bal = ballot(place);
-        const u32 j = jBase + popc64(bal & lanemask_lt());
-        jBase += popc64(bal);
-        if (place) {
-            u32 lo = 0, hi = 63;
-#pragma unroll
-            for (u32 it = 0; it < 6; ++it) { const u32 mid = (lo + hi + 1) >> 1; if (cumR[mid] <= j) lo = mid; else hi = mid - 1; }
-            tableSymbol[p] = (u8)lo;
-        }
-    }
-    wave_lds_sync();
-    u32 nxt = total;                                       // cumul[lane], advanced as cells of symbol `lane` are met
-    for (u32 u0 = 0; u0 < tableSize; u0 += 64) {
-        const u32 u = u0 + lane; const bool valid = u < tableSize;
-        const u32 sym = valid ? tableSymbol[u] : 0xFFFFu;
-        u64 rem = ballot(valid);
-        while (rem) {
-            const u32 s0 = read_lane(sym, ctz64(rem));
-            const u64 m = ballot(sym == s0);
-            const u32 baseN = read_lane(nxt, s0);
-            if (sym == s0) stateTable[baseN + popc64(m & lanemask_lt())] = (u16)(tableSize + u);
-            nxt = lane == s0 ? nxt + popc64(m) : nxt;
-            rem &= ~m;
-        }
-    }
-    if (lane <= maxSV) {
-        SymTT t;
-        if (nc == 0) { t.deltaNbBits = ((tableLog + 1) << 16) - (1u << tableLog); t.deltaFindState = 0; }
-        else if (nc == -1 || nc == 1) { t.deltaNbBits = (tableLog << 16) - (1u << tableLog); t.deltaFindState = (s32)(total - 1); }
-        else {
-            const u32 maxBitsOut = tableLog - highbit32((u32)nc - 1);
-            t.deltaNbBits = (maxBitsOut << 16) - ((u32)nc << maxBitsOut);
-            t.deltaFindState = (s32)(total - (u32)nc);
-        }
-        tt[lane] = t;
-    }
-    wave_lds_sync();
-}
-
 // ZSTD_selectEncodingType + ZSTD_buildCTable for one of LL/OF/ML, whole wave: the decisions, FSE_normalizeCount and
 // FSE_writeNCount run on lane 0 (short), the table itself is built by all lanes.  Returns bytes written to `op` (uniform).
 __device__ __forceinline__ u32 build_seq_table(SeqWaveLds& W, u8* op, u32* count, u32 maxPossible, u32 FSELog, u32 nbSeq, u32 lastCode,
