@@ -1,4 +1,4 @@
-// zmi_fse.h — device-side FSE (tANS) table construction, run by ONE lane per block.
+// zmi_fse.h — device-side FSE (tANS) table construction: the short serial sections run by ONE lane per block, the table itself by the wave.
 //
 // These are the per-block serial sections of the entropy stage: a few dozen symbols
 // and tables of <= 512 states.  They follow the reference step for step so that the emitted headers and tables
@@ -145,47 +145,6 @@ __device__ inline u32 fse_write_ncount(u8* out, const s16* norm, u32 maxSV, u32 
     return (u32)(out - ostart);
 }
 
-// stateTable: 1<<tableLog entries; tt: maxSV+1 entries; scratch: cumul u16[maxSV+2], tableSymbol u8[1<<tableLog]
-__device__ inline void fse_build_ctable(u16* stateTable, SymTT* tt, const s16* norm, u32 maxSV, u32 tableLog,
-                                        u16* cumul, u8* tableSymbol)
-{
-    const u32 tableSize = 1u << tableLog, tableMask = tableSize - 1;
-    const u32 step = (tableSize >> 1) + (tableSize >> 3) + 3;
-    u32 highThreshold = tableSize - 1;
-    cumul[0] = 0;
-    for (u32 u = 1; u <= maxSV + 1; u++) {
-        if (norm[u - 1] == -1) { cumul[u] = cumul[u - 1] + 1; tableSymbol[highThreshold--] = (u8)(u - 1); }
-        else cumul[u] = cumul[u - 1] + (u16)norm[u - 1];
-    }
-    cumul[maxSV + 1] = (u16)(tableSize + 1);
-    {
-        u32 position = 0;
-        for (u32 symbol = 0; symbol <= maxSV; symbol++) {
-            for (int k = 0; k < norm[symbol]; k++) {
-                tableSymbol[position] = (u8)symbol;
-                position = (position + step) & tableMask;
-                while (position > highThreshold) position = (position + step) & tableMask;
-            }
-        }
-    }
-    for (u32 u = 0; u < tableSize; u++) { const u8 s = tableSymbol[u]; stateTable[cumul[s]++] = (u16)(tableSize + u); }
-    u32 total = 0;
-    for (u32 s = 0; s <= maxSV; s++) {
-        const int nc = norm[s];
-        if (nc == 0) { tt[s].deltaNbBits = ((tableLog + 1) << 16) - (1u << tableLog); tt[s].deltaFindState = 0; }
-        else if (nc == -1 || nc == 1) {
-            tt[s].deltaNbBits = (tableLog << 16) - (1u << tableLog);
-            tt[s].deltaFindState = (s32)(total - 1); total++;
-        } else {
-            const u32 maxBitsOut = tableLog - highbit32((u32)nc - 1);
-            const u32 minStatePlus = (u32)nc << maxBitsOut;
-            tt[s].deltaNbBits = (maxBitsOut << 16) - minStatePlus;
-            tt[s].deltaFindState = (s32)(total - (u32)nc);
-            total += (u32)nc;
-        }
-    }
-}
-
 // FSE_buildCTable_wksp (U/FseCompress.cs:20-160) by the 64 lanes of the chunk's wave; lane s stands for symbol s.  Same
 // restatement as the decoder's table build (decode.hip): low-probability symbols take the top cells in symbol order; the
 // reference's spreading visits (i*step) & mask for i = 0, 1, ... and skips cells above highThreshold, so the j-th cell it
@@ -255,23 +214,5 @@ __device__ __forceinline__ u32 fse_init_state2(const u16* stateTable, const SymT
     const u32 v = (nbBitsOut << 16) - t.deltaNbBits;
     return stateTable[(s32)(v >> nbBitsOut) + t.deltaFindState];
 }
-
-// serial LSB-first bit writer into byte-addressable memory (U/Bitstream.cs:87-160)
-struct BitW {
-    u8* p; u64 acc; u32 nbits;
-    __device__ __forceinline__ void init(u8* dst) { p = dst; acc = 0; nbits = 0; }
-    __device__ __forceinline__ void add(u32 value, u32 n)
-    {
-        acc |= (u64)(value & ((n >= 32) ? 0xFFFFFFFFu : ((1u << n) - 1))) << nbits; nbits += n;
-        if (nbits >= 32) { *(u32u*)p = (u32)acc; p += 4; acc >>= 32; nbits -= 32; }
-    }
-    // end mark + flush; returns one past the last byte written
-    __device__ __forceinline__ u8* close()
-    {
-        add(1, 1);
-        while (nbits > 0) { *p++ = (u8)acc; acc >>= 8; nbits = nbits > 8 ? nbits - 8 : 0; }
-        return p;
-    }
-};
 
 } // namespace zmi
