@@ -158,6 +158,9 @@ size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* dctx, unsigned mode);
 /* the literal decoder beside the sequence decoder on a second stream (they need nothing of each other): 0 = when a call has few
  * blocks (default: neither kernel fills the chip then), 1 = never, 2 = always */
 size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* dctx, unsigned mode);
+/* waves per frame in the match-execution stage: 0 = by the number of frames in the call (default: few frames get up to 16 waves
+ * each — a batch of 64 x waves sequences per round of dependent copies —, more than 2048 frames one wave each), else 1, 2, 4, 8 or 16 */
+size_t ZSTDMI_DCtx_setExecWaves(ZSTD_DCtx* dctx, unsigned waves);
 
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
 size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);

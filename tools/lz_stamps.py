@@ -14,7 +14,7 @@ enames = ["repcodes", "histograms", "tables (lane 0)", "pack+flush (+batch load)
 snames = ["other", "state chain", "fields+reps", "literals", "indep matches", "dependent matches"]
 hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHeight", "codes+bits", "weights+final"]
 names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense tile: select", "dense tile: finish+rank", "region: candidates (I)", "region: load pass", "region: speculative parse", "region: real parse", "region: links+scans", "region: emit+literals"]
-n = 256 << 20
+n = (int(sys.argv[1]) if len(sys.argv) > 1 else 256) << 20
 for kind in ("zipf", "text"):
     host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), 8)[:n]
     src = torch.from_numpy(host.copy()).cuda(); torch.cuda.synchronize()

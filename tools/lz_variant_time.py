@@ -25,4 +25,4 @@ for _ in range(3): cs = lib.ZSTDMI_compressDevice(c, dst.data_ptr(), cap, src.da
 ms = (ctypes.c_float * 16)(); names = (ctypes.c_char_p * 16)()
 k = lib.ZSTDMI_CCtx_getStageTimes(c, ms, names, 16)
 st = {names[i].decode(): ms[i] for i in range(k)}
-print(f"{libs[0]:40s} searchLog {sl} level {level} {kind}: lz {st.get('lz_fast', 0) * 4:.2f} ms/GiB  ratio {cs / n:.5f}", flush=True)
+print(f"{libs[0]:40s} searchLog {sl} level {level} {kind}: lz {st.get('lz_fast', 0) * 4:.2f} + region {st.get('lz_region', 0) * 4:.2f} ms/GiB  ratio {cs / n:.5f}", flush=True)

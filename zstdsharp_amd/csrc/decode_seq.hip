@@ -647,9 +647,172 @@ __global__ __launch_bounds__(64) void exec_matches_kernel(const u8* __restrict__
     }
 }
 
-void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
-                         const u8* dict, u32 dictSize, hipStream_t stream)
+// ------------------------------------------------------------------------------------------------
+// exec_matches on FEW frames: W waves per frame.  With one wave per frame what a frame costs is its number of dependency rounds
+// (a round = stores acknowledged, barrier, loads: about a microsecond, whatever it copies), and 1024 frames of 1 MiB leave three
+// quarters of the chip's wave slots empty.  Here a batch is 64 x W sequences, one per thread of a W-wave workgroup: the chain of
+// matches that read each other's output grows far slower than the batch (oracle level-5 text, rounds per sequence: 0.050 at
+// 64, 0.027 at 256, 0.021 at 512), so a frame needs about half the rounds at W = 4, two fifths at W = 8.
+// Same rules as above: outputs lie in sequence order, a match depends on the earlier matches of its batch whose output its source
+// touches (an index interval, found by binary search over the batch's bounds in LDS), a round runs every match whose interval is
+// complete.  The done bits are double-buffered by round parity, so one barrier per round is enough.
+// ------------------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(64 * W) void exec_matches_wide_kernel(const u8* __restrict__ src, u8* __restrict__ out, const FrameDesc* __restrict__ frames,
+                                                                   const BlockDesc* __restrict__ blocks, u32 nFrames, const SeqRec* __restrict__ recs,
+                                                                   u32* __restrict__ status, const u8* __restrict__ dict, const u32 dictSize)
 {
+    constexpr u32 kB = 64u * W;                                  // sequences per batch
+    __shared__ u32 endOfOut[kB], startOfOut[kB];                 // block-relative bounds of the batch's match outputs (monotone; 0xFFFFFFFF: no sequence)
+    __shared__ u64 doneBits[2][W];
+    __shared__ u32 waveSum[W];
+    __shared__ u32 errFlag;
+    const u32 f = blockIdx.x, tid = threadIdx.x, lane = tid & 63u, wave = uniform(tid >> 6);
+    if (f >= nFrames || status[kStErr]) return;
+    const FrameDesc& F = frames[f];
+    if (F.bad || !(F.hasSeq || F.checksum)) return;
+    const bool viaOrigin = uniform(F.viaOrigin) != 0;
+    if (viaOrigin && !F.checksum) return;
+    u8* const fout = out + F.dstOff;
+    const u32 first = uniform(F.firstBlock), nb = uniform(F.nbBlocks);
+    if (tid == 0) errFlag = 0;
+    __syncthreads();
+    u32 err = 0, errBlock = first;
+    for (u32 k = 0; k < nb && !err && F.hasSeq && !viaOrigin; ++k) {
+        const BlockDesc& B = blocks[first + k];
+        const u32 nbSeq = uniform(B.type == 2 ? B.nbSeq : 0u);
+        if (!nbSeq) continue;
+        const u64 bRel = B.dstRel;
+        u8* const o = fout + bRel;
+        const u32 in0 = uniform(B.repIn[0]), in1 = uniform(B.repIn[1]), in2 = uniform(B.repIn[2]);
+        const SeqRec* __restrict__ const rec = recs + B.seqBase;
+        SeqRec rNext; rNext.lo = 0; rNext.hi = 0;
+        if (tid < nbSeq) rNext = rec[tid];
+        u32 outBase = 0;
+        for (u32 base = 0; base < nbSeq; base += kB) {
+            const bool have = base + tid < nbSeq;
+            const SeqRec r = rNext;
+            if (base + kB + tid < nbSeq) rNext = rec[base + kB + tid];
+            u32 ll = 0, ml = 0, off = 1;
+            if (have) {
+                u32 tag; rec_unpack(r, ll, ml, off, tag);
+                if (tag) { const u32 in = tag == 1 ? in0 : tag == 2 ? in1 : in2; off = in > off ? in - off : 1u; }
+            }
+            const u32 incl = wave_scan_incl(ll + ml);
+            if (lane == 63) waveSum[wave] = incl;
+            __syncthreads();                                     // (also: nobody still reads the previous batch's bounds or done bits)
+            u32 before = 0, total = 0;
+#pragma unroll
+            for (u32 w = 0; w < (u32)W; ++w) { const u32 v = waveSum[w]; if (w < wave) before += v; total += v; }
+            const u32 pos = outBase + before + incl - ll - ml;
+            outBase += total;
+            const u32 dMatch = pos + ll;
+            if (have && ((u64)off > bRel + dMatch + dictSize || off == 0)) errFlag = 1;       // (:2218-2223)
+            u32 dictN = 0;
+            if (dictSize) {                                      // uniform: a match that starts in the dictionary (:2223-2250)
+                if (have && (u64)off > bRel + dMatch && (u64)off <= bRel + dMatch + dictSize) {
+                    const u32 back = (u32)((u64)off - (bRel + dMatch));
+                    dictN = back < ml ? back : ml;
+                    const u8* ds = dict + (dictSize - back);
+                    for (u32 i = 0; i < dictN; i++) o[dMatch + i] = ds[i];
+                }
+            }
+            const u32 dMatchR = dMatch + dictN, mlR = ml - dictN;
+            const bool hasMatch = have && mlR != 0;
+            const s64 srcLo = (s64)dMatchR - (s64)off, srcHi = srcLo + (s64)(off < mlR ? off : mlR);
+            endOfOut[tid] = have ? dMatch + ml : 0xFFFFFFFFu; startOfOut[tid] = have ? dMatch : 0xFFFFFFFFu;
+            {
+                const u64 mm = ballot(hasMatch);
+                if (lane == 0) doneBits[0][wave] = ~mm;           // lanes without a match never block anyone
+            }
+            __syncthreads();                                     // bounds, done bits, errFlag; output of earlier batches visible
+            if (errFlag) { err = kErrCorruption; errBlock = first + k; break; }      // uniform
+            // earlier sequences of the batch whose match output overlaps my source: [jl, jh)
+            u32 jl = 0, jh = 0;
+            if (hasMatch && srcHi > 0) {
+                const u32 lo32 = srcLo > 0 ? (u32)srcLo : 0u, hi32 = (u32)srcHi;
+#pragma unroll
+                for (u32 st = kB >> 1; st; st >>= 1) {
+                    if (endOfOut[jl + st - 1] <= lo32) jl += st;
+                    if (startOfOut[jh + st - 1] < hi32) jh += st;
+                }
+                if (jh > tid) jh = tid;
+            }
+            bool mine = hasMatch;
+            const bool longM = mlR > 64;
+            for (u32 round = 0; ; ++round) {
+                const u64* const D = doneBits[round & 1];
+                u64 all = ~0ull, own = 0;
+#pragma unroll
+                for (u32 w = 0; w < (u32)W; ++w) { const u64 d = D[w]; all &= d; if (w == wave) own = d; }
+                if (all == ~0ull) break;                         // uniform: everybody reads the same words
+                bool ready = mine;
+                if (ready && jh > jl) {
+                    for (u32 w = jl >> 6; w <= ((jh - 1) >> 6); ++w) {
+                        u64 bits = ~0ull;
+                        if (w == (jl >> 6)) bits &= ~0ull << (jl & 63u);
+                        if (w == ((jh - 1) >> 6)) bits &= ~0ull >> (63u - ((jh - 1) & 63u));
+                        if (bits & ~D[w]) { ready = false; break; }
+                    }
+                }
+                if (ready && !longM) lane_match_copy(o + dMatchR, off, mlR);
+                u64 lm = ballot(ready && longM);
+                while (lm) {
+                    const u32 i = ctz64(lm); lm &= lm - 1;
+                    wave_match_copy(o + read_lane(dMatchR, i), read_lane(off, i), read_lane(mlR, i), lane);
+                }
+                const u64 rdy = ballot(ready);
+                mine = mine && !ready;
+                if (lane == 0) doneBits[(round + 1) & 1][wave] = own | rdy;
+                __syncthreads();                                 // this round's bytes are visible to the workgroup
+            }
+        }
+    }
+    if (err) { if (tid == 0) report_error(status, errBlock, kStageExec, err); return; }
+    if (F.checksum && wave == 0) {
+        // XXH64 of the regenerated frame, as in the one-wave kernel (U/ZstdDecompress.cs:1186-1208)
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        const u64 P1 = 0x9E3779B185EBCA87ULL, P2 = 0xC2B2AE3D27D4EB4FULL, P3 = 0x165667B19E3779F9ULL, P4 = 0x85EBCA77C2B2AE63ULL, P5 = 0x27D4EB2F165667C5ULL;
+        auto rotl = [](u64 x, int r) { return (x << r) | (x >> (64 - r)); };
+        auto rnd = [&](u64 acc, u64 in) { acc += in * P2; acc = rotl(acc, 31); return acc * P1; };
+        const u64 n = F.dstSize, stripes = n >> 5; const u32 j = lane & 3;
+        u64 v = j == 0 ? P1 + P2 : j == 1 ? P2 : j == 2 ? 0 : 0 - P1;
+        if (lane < 4) for (u64 i = 0; i < stripes; i++) v = rnd(v, readLE64(fout + 32 * i + 8 * j));
+        const u64 v1 = __shfl(v, 0), v2 = __shfl(v, 1), v3 = __shfl(v, 2), v4 = __shfl(v, 3);
+        u32 bad = 0;
+        if (lane == 0) {
+            u64 hh;
+            if (n >= 32) {
+                hh = rotl(v1, 1) + rotl(v2, 7) + rotl(v3, 12) + rotl(v4, 18);
+                auto mrg = [&](u64 acc, u64 x) { acc ^= rnd(0, x); return acc * P1 + P4; };
+                hh = mrg(hh, v1); hh = mrg(hh, v2); hh = mrg(hh, v3); hh = mrg(hh, v4);
+            } else hh = P5;
+            hh += n;
+            const u8* q = fout + (stripes << 5); const u8* const end = fout + n;
+            while (q + 8 <= end) { hh ^= rnd(0, readLE64(q)); hh = rotl(hh, 27) * P1 + P4; q += 8; }
+            if (q + 4 <= end) { hh ^= (u64)readLE32(q) * P1; hh = rotl(hh, 23) * P2 + P3; q += 4; }
+            while (q < end) { hh ^= (*q) * P5; hh = rotl(hh, 11) * P1; q++; }
+            hh ^= hh >> 33; hh *= P2; hh ^= hh >> 29; hh *= P3; hh ^= hh >> 32;
+            if ((u32)hh != readLE32(src + F.srcOff + F.srcSize - 4)) bad = 1;
+        }
+        if (uniform(bad) && lane == 0) report_error(status, (u64)first + nb - 1, kStageFrameEnd, kErrChecksumWrong);
+    }
+}
+
+// wide: waves per frame.  Measured on 1 MiB level-5 frames (exec_matches, ms; tools/exec_waves_time.py): 256 frames: 1 wave 5.0,
+// 16 waves 2.4; 1024 frames: 6.8 / 5.5 / 4.3 / 5.7 / 7.3 at 1 / 2 / 4 / 8 / 16; 2048 frames: 8.3 / 6.5 / 8.0 at 1 / 2 / 4; 4096
+// frames: 9.8 / 12.3 at 1 / 2 — i.e. as many waves as keep frames x waves at about 4096 (the caller's rule, decompress_device)
+void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
+                         const u8* dict, u32 dictSize, hipStream_t stream, int wide)
+{
+    const u32 ds = dict ? dictSize : 0u;
+    switch (wide) {
+    case 16: hipLaunchKernelGGL(exec_matches_wide_kernel<16>, dim3(nFrames), dim3(1024), 0, stream, src, out, frames, blocks, nFrames, recs, status, dict, ds); return;
+    case 8:  hipLaunchKernelGGL(exec_matches_wide_kernel<8>,  dim3(nFrames), dim3(512),  0, stream, src, out, frames, blocks, nFrames, recs, status, dict, ds); return;
+    case 4:  hipLaunchKernelGGL(exec_matches_wide_kernel<4>,  dim3(nFrames), dim3(256),  0, stream, src, out, frames, blocks, nFrames, recs, status, dict, ds); return;
+    case 2:  hipLaunchKernelGGL(exec_matches_wide_kernel<2>,  dim3(nFrames), dim3(128),  0, stream, src, out, frames, blocks, nFrames, recs, status, dict, ds); return;
+    default: break;
+    }
     // dict: a raw-content dictionary (or a formatted one's content) = history in front of EVERY frame (ZSTD_refDictContent,
     // U/ZstdDecompress.cs:1758-1771); may be null
     hipLaunchKernelGGL(exec_matches_kernel, dim3(nFrames), dim3(64), 0, stream, src, out, frames, blocks, nFrames, recs, status, dict, dict ? dictSize : 0u);

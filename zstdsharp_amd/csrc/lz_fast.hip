@@ -85,7 +85,9 @@ struct LzLds {
     u64 nzWords[3];                      // bit g = matchMask[g] != 0 (accumulated with atomicOr during verify)
     u32 matchCount[3];                   // matches in the current tile (decides sparse / dense selection)
     u16 sparseList[64];                  // sparse path: the tile's matches in position order
+    u32 claim;                           // the chunk this workgroup takes next (lz_kernel with a claim counter)
 };
+static_assert(sizeof(LzLds) <= 160u * 1024u, "a workgroup's LDS");
 
 // hash of the 6 bytes at a position (the reference's ZSTD_hash6 needs a 64x64-bit multiply, four quarter-rate VALU
 // multiplies per lane; two 32-bit multiplies over the same six bytes mix as well for a 13-bit table)
@@ -518,6 +520,9 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
 #ifdef ZMI_LZ_STAMPS
     unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
+#if defined(ZMI_EXP_STOP) && ZMI_EXP_STOP == 1
+    return;
+#endif
     // ---------------- I: candidates of every position, tile by tile ----------------
     if constexpr (MODE == 2) hc_tiles(L, n, lowLimit >> kTileLog, nTiles, fromTile, lowLimit, hcDepth, candG, chainG, tid, lane, wave
 #ifdef ZMI_LZ_STAMPS
@@ -527,6 +532,9 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
     else insert_tiles<MODE>(L, n, insertFrom, nTiles, fromTile, lowLimit, candG, tid);      // (MODE 2 always comes with its chain plane)
     __syncthreads();
     ZMI_DSTAMP(10);
+#if defined(ZMI_EXP_STOP) && ZMI_EXP_STOP == 2
+    return;
+#endif
     if (deferred) {                                       // (uniform) the bytes counted so far, out of LDS (see the tile loop)
         for (u32 q16 = tid * 16; q16 < litBase; q16 += kTile * 16) {
             const uint4 v = *reinterpret_cast<const uint4*>(L.in + hist + q16);
@@ -540,6 +548,19 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
     for (u32 lo = fromTile * kTilePos; lo < n; lo += kPassPos) {
         const u32 hi = lo + kPassPos < n ? lo + kPassPos : n;
         const u32 nReg = (hi - lo + 63) >> 6;
+#ifdef ZMI_EXP_LOAD2
+        for (u32 rep = 0; rep < ZMI_EXP_LOAD2; ++rep) {
+            const u32 cnt = hi - lo + 64;
+            uint4 v[4];
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) { const u32 i = (tid + k * kTile) * 8; v[k] = *reinterpret_cast<const uint4*>(candG + lo + (i < cnt ? i : 0)); }
+#pragma unroll
+            for (u32 k = 0; k < 4; ++k) { const u32 i = (tid + k * kTile) * 8; if (i < cnt) *reinterpret_cast<uint4*>(C + i) = v[k]; }
+            lds_barrier();
+            asm volatile("" ::: "memory");
+        }
+#endif
         {   // candidates of the pass (+ one region: a lane's stretch may reach that far): global (L2) -> LDS, 16 bytes per lane,
             // the four loads of a thread in flight together
             const u32 cnt = hi - lo + 64;
@@ -591,6 +612,9 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
         constexpr u32 kWarm = 16;
         const bool lastReg = tid + 1 == nReg;
         u32 eSpec = 0;
+#ifdef ZMI_EXP_SPEC
+        for (u32 rep = 0; rep < ZMI_EXP_SPEC; ++rep)
+#endif
         if (mine) {
             u32 p = tid == 0 ? rs : rs - kWarm;
             if (p < cursor) p = cursor;
@@ -784,17 +808,25 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                                                   Seq* __restrict__ seqs, u8* __restrict__ lits,
                                                   ChunkMeta* __restrict__ meta,
                                                   const u8* __restrict__ prefixArg, const u32 prefixLenArg, const u32 chunkBytes,
-                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocksArg, u16* __restrict__ candAll, u16* __restrict__ chainAll, u32* __restrict__ regionList, const u32 nChunks)
+                                                  const u32 fhExtra, const u32 minStrideLog, const u32 frameBlocksArg, u16* __restrict__ candAll, u16* __restrict__ chainAll, u32* __restrict__ regionList, const u32 nChunks,
+                                                  u32* __restrict__ claimCtr)
 {
     extern __shared__ __attribute__((aligned(16))) u8 ldsRaw[];
     LzLds& L = *reinterpret_cast<LzLds*>(ldsRaw);
     const u32 tid = threadIdx.x, lane = lane_id(), wave = uniform(wave_id());
-    // A workgroup takes chunks blockIdx.x, + gridDim.x, ...: with one workgroup per CU (LDS) nothing else hides the load latency at
-    // the start of a chunk, so the NEXT chunk's bytes are fetched into registers while this one is parsed (plain chunks only:
-    // a dictionary or history in front of the chunk keeps the direct path).
+    // With one workgroup per CU (LDS) nothing else hides the load latency at the start of a chunk, so the NEXT chunk's bytes are
+    // fetched into registers while this one is parsed (plain chunks only: a dictionary or history in front of the chunk keeps the
+    // direct path).  Which chunk is next: claimCtr == null: c + gridDim.x.  Otherwise (a grid of one workgroup per CU) the
+    // workgroups CLAIM chunks from a counter as they go — chunks of unequal cost balance by themselves, and every chunk but a
+    // workgroup's first arrives prefetched (a stamped build had 42 % of an unprefetched Zipf chunk's time in this load).  The claim
+    // is made one chunk ahead of the prefetch (thread 0 holds the answer in a register through a chunk), so nobody waits for it.
     constexpr bool kPrefetch = MODE == 0 && !DICT && !FAR;      // (the dual-hash finders have no 16 registers to spare)
     uint4 pf0 = {0, 0, 0, 0}, pf1 = pf0, pf2 = pf0, pf3 = pf0; bool pfValid = false;
-    for (u32 c = blockIdx.x; c < nChunks; c += gridDim.x) {
+    const bool claiming = kPrefetch && claimCtr != nullptr;     // uniform
+    u32 claimed = 0;                                            // thread 0: the chunk after the next
+    if (claiming && tid == 0) claimed = atomicAdd(claimCtr, 1u) + gridDim.x;
+    u32 cNext = 0;
+    for (u32 c = blockIdx.x; c < nChunks; c = cNext) {
     // Raw-content dictionary (row f-4; ZSTD_loadDictionaryContent, U/ZstdCompress.cs:5126-5237): its last `prefixLen` bytes
     // sit in front of the chunk in LDS, ending at a tile boundary (hist = whole tiles of history, positions below lowLimit
     // are padding and never referenced).  History tiles only go into the tables (insert_tiles); the parse starts
@@ -878,8 +910,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     }
     if (tid == 0) { L.nzWords[0] = 0; L.nzWords[1] = 0; L.nzWords[2] = 0; L.matchCount[0] = 0; L.matchCount[1] = 0; L.matchCount[2] = 0; }
     pfValid = false;
+    cNext = c + gridDim.x;
+    if (claiming && tid == 0) { L.claim = claimed; claimed = atomicAdd(claimCtr, 1u) + gridDim.x; }
+    __syncthreads();
+    if (claiming) cNext = L.claim;
     if (kPrefetch) {
-        const u32 cN = c + gridDim.x;
+        const u32 cN = cNext;
         const u8* __restrict__ inN = src + (u64)cN * kChunkSize;
         if (cN < nChunks && srcSize - (u64)cN * kChunkSize >= kChunkSize && (((uintptr_t)inN) & 15) == 0) {      // uniform
             const uint4* n4 = reinterpret_cast<const uint4*>(inN);
@@ -887,7 +923,6 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             pfValid = true;
         }
     }
-    __syncthreads();
     if (FAR && farAvail) {
         // the table starts out holding the input in front of the block (what the reference's table still holds from the blocks
         // before, U/ZstdFast.cs:9-46): latest occurrence per bucket, straight from global memory
@@ -1557,7 +1592,9 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
     const ChunkMeta m0 = meta[c];
     u32 cursor = rc - 1, nbSeq = m0.nbSeq, litBase = m0.litSize; bool deferred = m0.litFromSrc != 0;
     const u32 nTiles = (n + kTilePos - 1) / kTilePos;
-    dense_rest<MODE>(L, n, insertFrom, (hist >> kTileLog) + 1, nTiles, hist, lowLimit, candAll + (u64)c * kChunkSize, chainAll ? chainAll + (u64)c * kChunkSize : nullptr, hcDepth,
+    // (candidate and link planes belong to the WORKGROUP, not to the chunk: written and read back within a chunk's time, the same
+    //  128 KiB per CU again and again stay in L2 / the memory-side cache instead of travelling to HBM and back)
+    dense_rest<MODE>(L, n, insertFrom, (hist >> kTileLog) + 1, nTiles, hist, lowLimit, candAll + (u64)blockIdx.x * kChunkSize, chainAll ? chainAll + (u64)blockIdx.x * kChunkSize : nullptr, hcDepth,
                      seqs + (u64)c * kMaxSeq, lits + (u64)c * kLitStride, cursor, nbSeq, litBase, deferred, tid, lane, wave);
     if (tid == 0) { meta[c].nbSeq = nbSeq; meta[c].litSize = litBase; meta[c].litFromSrc = deferred ? 1u : 0u; }
     __syncthreads();                                       // the next chunk takes over LDS
@@ -1633,7 +1670,7 @@ extern "C" void ZSTDMI_debugReadLzStamps(unsigned long long* out16, int reset)
 
 template <int MODE, int SHORT, bool DICT, bool FAR = false>
 static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook)
+                       u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook, u32* claimCtr)
 {
     // the region parse of dense chunks: a second kernel behind a work list (see lz_region_kernel), inlined for the others
     constexpr bool kSplit = (MODE == 0 && !DICT && !FAR) || MODE == 2;
@@ -1647,10 +1684,14 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
     }
     if (FAR) cand = nullptr;
     if (cand && kSplit) (void)hipMemsetAsync(regionList, 0, sizeof(u32), stream);
-    // (the fast finder on plain chunks: 4096 workgroups — 1024 balanced mixed data visibly worse —, each takes every 4096th chunk with the next one's bytes in flight; the hardware
-    //  still hands workgroups to CUs as they free up, which is what balances chunks of unequal cost.  Everything else: a workgroup per chunk)
-    const u32 grid = (MODE == 0 && !DICT && !FAR && nChunks > 4096) ? 4096u : nChunks;
-    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, cand ? chain : nullptr, cand ? regionList : nullptr, nChunks);
+    // the fast finder on plain chunks, more chunks than CUs: one workgroup per CU, chunks claimed from a counter (see lz_kernel)
+    static u32 cuCount[64] = {};
+    if (!cuCount[dev & 63]) { int n = 0; (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); cuCount[dev & 63] = n > 0 ? (u32)n : 256u; }
+    const bool claim = MODE == 0 && !DICT && !FAR && claimCtr && nChunks > cuCount[dev & 63];
+    if (claim) (void)hipMemsetAsync(claimCtr, 0, sizeof(u32), stream);
+    const u32 grid = claim ? cuCount[dev & 63] : nChunks;
+    hipLaunchKernelGGL((lz_kernel<MODE, SHORT, DICT, FAR>), dim3(grid), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, cand ? chain : nullptr, cand ? regionList : nullptr, nChunks,
+                       claim ? claimCtr : nullptr);
     hook("lz_fast");
     if constexpr (kSplit) if (cand) {                      // the dense chunks' rest: 256 workgroups (one per CU) walk the list
         hipLaunchKernelGGL((lz_region_kernel<MODE, DICT>), dim3(nChunks < 256 ? nChunks : 256), dim3(kTile), sizeof(LzLds), stream, src, srcSize, seqs, lits, meta, cand, chain, regionList,
@@ -1667,24 +1708,24 @@ static void launch_one(const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* l
 // frames of chunkBytes each (ZSTD_c_windowLog 10 .. 15: a frame is its own window), on the same instantiation with an empty history.
 // cand / regionList (null: off): workspace of the region parse, 65536 u16 per chunk and 1 + nChunks u32.
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook)
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook, u32* claimCtr)
 {
     if (chunkBytes >= kChunkSize && frameBlocks && finder == 0) {       // fast strategy with cross-chunk history: full 64 KiB blocks, far candidates
-        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, nullptr, 0, stream, hook);
+        launch_one<0, 5, false, true>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, frameBlocks, nullptr, nullptr, nullptr, 0, stream, hook, claimCtr);
         return;
     }
     if (chunkBytes >= kChunkSize) {
         switch (finder) {
-        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook); break;
-        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook); break;
-        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook); break;
+        case 0:  launch_one<0, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook, claimCtr); break;
+        case 1:  launch_one<1, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook, claimCtr); break;
+        default: launch_one<2, 5, false>(src, srcSize, nChunks, seqs, lits, meta, nullptr, 0, kChunkSize, fhExtra, minStrideLog, 0, cand, chain, regionList, hcDepth, stream, hook, claimCtr); break;
         }
         return;
     }
     switch (finder) {
-    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook); break;
-    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook); break;
-    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook); break;
+    case 0:  launch_one<0, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook, claimCtr); break;
+    case 1:  launch_one<1, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook, claimCtr); break;
+    default: launch_one<2, 5, true>(src, srcSize, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, fhExtra, minStrideLog, frameBlocks, cand, chain, regionList, hcDepth, stream, hook, claimCtr); break;
     }
 }
 

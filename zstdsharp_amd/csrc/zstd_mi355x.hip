@@ -19,7 +19,7 @@
 namespace zmi {
 // kernels (lz_fast.hip, huf_enc.hip, seq_enc.hip, frame.hip, decode.hip)
 void launch_lz(u32 finder, const u8* src, u64 srcSize, u32 nChunks, Seq* seqs, u8* lits, ChunkMeta* meta, const u8* prefix, u32 prefixLen,
-               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook);
+               u32 chunkBytes, u32 fhExtra, u32 minStrideLog, u32 frameBlocks, u16* cand, u16* chain, u32* regionList, u32 hcDepth, hipStream_t stream, StageHook hook, u32* claimCtr);
 void launch_lz_probe(const u8* src, u64 srcSize, u64 front, u64 groupBytes, u32 nGroups, u32 tilesPerGroup, u32* out, hipStream_t stream);
 void launch_huf_build(const u8* lits, ChunkMeta* meta, HufTable* tables, u8* slots, u32 nChunks, u32 rawLiterals, const u8* src, u32 chunkBytes,
                       hipStream_t stream, StageHook hook);
@@ -47,7 +47,7 @@ void launch_decode_literals(const u8* src, u8* out, u8* scratch, const FrameDesc
 void launch_place_literals(const u8* src, u8* out, const u8* scratch, const FrameDesc* frames, const BlockDesc* blocks, u32 nBlocks,
                            const SeqRec* recs, const u32* status, hipStream_t stream);
 void launch_exec_matches(const u8* src, u8* out, const FrameDesc* frames, const BlockDesc* blocks, u32 nFrames, const SeqRec* recs, u32* status,
-                         const u8* dict, u32 dictSize, hipStream_t stream);
+                         const u8* dict, u32 dictSize, hipStream_t stream, int wide);
 void launch_origin_select(FrameDesc* frames, u32 nFrames, u64 minBytes, u32* list, u32 listCap, u64 originCap, u32* status, hipStream_t stream);
 void launch_origin_init(const FrameDesc* frames, const BlockDesc* blocks, const u32* list, u32 listCap, u64 maxFrameBytes, const SeqRec* recs, u32* status,
                         u32* origin, u32 dictSize, hipStream_t stream);
@@ -181,6 +181,7 @@ struct ZSTD_DCtx_s {
     hipStream_t ownStream = nullptr, stream = nullptr;
     hipStream_t aux = nullptr; hipEvent_t auxDone = nullptr;     // the literal decoder beside seq_decode (decompress_device)
     int overlapMode = 0;        // ZSTDMI_DCtx_setOverlap: 0 = by block count, 1 = never, 2 = always
+    int execWaves = 0;          // ZSTDMI_DCtx_setExecWaves: waves per frame in exec_matches, 0 = by the number of frames
     DevBuf frames, blocks, recs, status, scratch, walkWs, slowFlags, stageSrc, stageDst, origin, originList;
     int originMode = 0;         // ZSTDMI_DCtx_setLongFrames: 0 = by cost (see decompress_device), 1 = never, 2 = every frame of 1 MiB or more
     StageTimer timer;
@@ -415,7 +416,7 @@ static size_t compress_range(ZSTD_CCtx* c, const CallParams& cp, u8* d_dst, size
         HufTable* tables = (HufTable*)c->tables.p; u8* slots = (u8*)c->slots.p; u64* offsets = (u64*)c->offsets.p; u64* total = (u64*)c->total.p;
         c->timer.begin(s);
         launch_lz(rs.finder, src, n, nChunks, seqs, lits, meta, prefix, prefixLen, chunkBytes, dictIdBytes | (cp.contentSizeFlag ? 0u : 0x100u) | (hdrWindow << 12), rs.minStrideLog, lzFrameBlocks, regionParse ? (u16*)c->cand.p : nullptr, hcChains ? (u16*)((u8*)c->cand.p + cand_plane_bytes(passChunks)) : nullptr,
-                  regionParse ? (u32*)((u8*)c->cand.p + cand_plane_bytes(passChunks) * (hcChains ? 2 : 1)) : nullptr, hcDepth, s, c->timer.hook());
+                  regionParse ? (u32*)((u8*)c->cand.p + cand_plane_bytes(passChunks) * (hcChains ? 2 : 1)) : nullptr, hcDepth, s, c->timer.hook(), (u32*)(total + 4));      // (the claim counter: a word of `total`'s 64 bytes)
         launch_huf_build(lits, meta, tables, slots, nChunks, rs.rawLiterals, src, chunkBytes, s, c->timer.hook());
         if (cp.checksumFlag) { launch_xxh64(src, n, meta, nChunks, chunkBytes, frameBlocks, s);             c->timer.mark("xxh64", s); }
         launch_seq_encode(seqs, meta, slots, nChunks, strategy, (cp.checksumFlag ? 1u : 0u) | (cp.contentSizeFlag ? 0u : 2u) | (hdrWindow << 8), 1, dictID, dictIdBytes, initReps, frameBlocks, chunkBytes, n, s);   c->timer.mark("seq_encode", s);
@@ -1033,13 +1034,16 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     d->timer.mark("block_prepass", s);
     const u64 nSeq = (u64)st[kStSeqLo] | ((u64)st[kStSeqHi] << 32);
     if (!d->recs.ensure((size_t)(nSeq + 64) * sizeof(SeqRec))) return ZERR(kErrMemoryAllocation);
-    // Long frames (decode_origin.hip).  The ordered walk of exec_matches moves a frame at about kWalkRate on one wave, all frames at
+    // Long frames (decode_origin.hip).  The ordered walk of exec_matches moves a frame at about kWalkRate, all frames at
     // once; the origin path sweeps the frames it is given at about kSweepRate together.  A frame belongs on the origin path when its
     // own walk would outlast the sweep of every frame at least as long: the smallest size class 2^(20+k) with
     // 2^(20+k) / kWalkRate >= bytes(frames >= 2^(20+k)) / kSweepRate, from the per-class sums block_link filed.
     u64 originMin = 0, originBytes = 0, originLongest = 0; u32 originCap = 0;
+    // (the walk has 64 x W sequences in flight per frame, W waves by the number of frames: measured on 1 - 4 MiB level-5 frames)
+    const int execWaves = d->execWaves ? d->execWaves : nFrames <= 256 ? 16 : nFrames <= 512 ? 8 : nFrames <= 1024 ? 4 : nFrames <= 2048 ? 2 : 1;
     if (d->originMode != 1) {
-        constexpr double kWalkRate = 0.15e9, kSweepRate = 20e9;
+        const double kWalkRate = execWaves >= 16 ? 0.42e9 : execWaves == 8 ? 0.33e9 : execWaves == 4 ? 0.24e9 : execWaves == 2 ? 0.19e9 : 0.15e9;
+        constexpr double kSweepRate = 20e9;
         u64 above = 0;
         u64 sums[12];
         for (int k = 0; k < 12; ++k) sums[k] = (u64)st[kStBigBins + 2 * k] | ((u64)st[kStBigBins + 2 * k + 1] << 32);
@@ -1097,7 +1101,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
         d->timer.mark("origin_jump", s);
         launch_origin_gather(frames, list, originCap, longest, status, origin, d_dst, dictContent, s);    d->timer.mark("origin_gather", s);
     }
-    launch_exec_matches(d_src, d_dst, frames, blocks, nFrames, recs, status, dictContent, dictContentSize, s);  d->timer.mark("exec_matches", s);
+    launch_exec_matches(d_src, d_dst, frames, blocks, nFrames, recs, status, dictContent, dictContentSize, s, execWaves);  d->timer.mark("exec_matches", s);
     if (!read_status(st)) return ZERR(kErrGeneric);
     d->timer.finish();
     if (st[kStErrKeyLo] != 0xFFFFFFFFu || st[kStErrKeyHi] != 0xFFFFFFFFu) return ZERR(st[kStErrKeyLo] & 0xFFFFu);   // the first failing block's first error
@@ -1503,6 +1507,7 @@ size_t ZSTDMI_DCtx_setDevices(ZSTD_DCtx* d, const int* devices, int n)
 }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+size_t ZSTDMI_DCtx_setExecWaves(ZSTD_DCtx* d, unsigned waves) { if (!d || (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)) return ZERR(kErrParameterOutOfBound); d->execWaves = (int)waves; return 0; }
 size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->overlapMode = (int)mode; return 0; }
 size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->originMode = (int)mode; return 0; }
 size_t ZSTDMI_DCtx_setLiteralDecoder(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 3) return ZERR(kErrParameterOutOfBound); d->litDecoder = mode; return 0; }
