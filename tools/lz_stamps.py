@@ -16,7 +16,7 @@ hnames = ["hist", "decide+place", "bucket sort", "build tree", "depths", "maxHei
 names = ["stage", "probe(pre-A)", "barrier A", "verify(phase B)", "barrier B", "emit(+sparse)", "barrier C", "literals", "dense tile: select", "dense tile: finish+rank", "region: candidates (I)", "region: load pass", "region: speculative parse", "region: real parse", "region: links+scans", "region: emit+literals"]
 n = (int(sys.argv[1]) if len(sys.argv) > 1 else 256) << 20
 for kind in ("zipf", "text"):
-    host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), 8)[:n]
+    host = datagen.zipf_bytes(n, 3) if kind == "zipf" else np.tile(datagen.text_like(32 << 20, 7), (n + (32 << 20) - 1) // (32 << 20))[:n]
     src = torch.from_numpy(host.copy()).cuda(); torch.cuda.synchronize()
     cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
     c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, 1)

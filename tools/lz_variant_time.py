@@ -15,7 +15,7 @@ import zstdsharp_amd._ffi as ffi
 ffi.LIB_PATH = os.path.join(ROOT, "zstdsharp_amd", libs[0])
 lib = ffi.load()
 n = 256 << 20
-host = np.tile(datagen.text_like(32 << 20, 7), 8)[:n] if kind == "text" else np.frombuffer(datagen.gen(kind, 32 << 20, 5) * 8, dtype=np.uint8)[:n]
+host = np.tile(datagen.text_like(32 << 20, 7), (n + (32 << 20) - 1) // (32 << 20))[:n] if kind == "text" else np.frombuffer(datagen.gen(kind, 32 << 20, 5) * 8, dtype=np.uint8)[:n]
 src = torch.from_numpy(host.copy()).cuda(); torch.cuda.synchronize()
 cap = lib.ZSTD_compressBound(n); dst = torch.empty(cap, dtype=torch.uint8, device="cuda")
 c = lib.ZSTD_createCCtx(); lib.ZSTD_CCtx_setParameter(c, 100, level); lib.ZSTDMI_CCtx_setProfiling(c, 1)
