@@ -338,11 +338,10 @@ __device__ __forceinline__ void insert_tiles(LzLds& L, const u32 n, const u32 tF
 // size on text, -11 % on Python sources.
 // ---------------------------------------------------------------------------------------------------------------------
 constexpr u32 kHcCont  = 12;             // a position whose left neighbour holds a match this long takes its continuation unsearched
+constexpr u32 kHcRing = 4;               // tiles whose links stay in LDS: the current one and the three before it
 struct HcLds {                           // laid over the 64 KiB of the hash tables
     u32 table[1u << kHashLog];           // position + 1 of the hash's latest occurrence so far (0 = none)
-    u16 hashes[kTilePos];                // the tile's hashes (0xFFFF: not a position to link)
-    u16 pred[kTilePos];                  // the tile's links (position + 1, 0 = none)
-    u16 spare[2 * kTilePos];
+    u16 links[kHcRing * kTilePos];       // links (position + 1, 0 = none) of the last 16384 positions: the one of position p at p & 16383
 };
 static_assert(sizeof(HcLds) == sizeof(u32) * (2u << kHashLog), "HcLds fills the tables' place");
 
@@ -354,17 +353,16 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
                                          )
 {
     HcLds& Hc = *reinterpret_cast<HcLds*>(L.tabMem);
-    // the links of the three tiles before the current one stay in LDS too (over the tile loop's arrays, idle here)
-    constexpr u32 kRing = 3;
-    u16* const ring = reinterpret_cast<u16*>(&L.tileLen[0]);
-    static_assert(offsetof(LzLds, tileLen) + kRing * kTilePos * sizeof(u16) <= sizeof(LzLds), "link ring must fit behind the tables");
-    u16* const tilePred = Hc.pred;
+    // the tile's hashes (0xFFFF: not a position to link): over the tile loop's arrays, idle here
+    u16* const hashes = reinterpret_cast<u16*>(&L.tileLen[0]);
+    static_assert(offsetof(LzLds, tileLen) + kTilePos * sizeof(u16) <= sizeof(LzLds), "the hashes must fit behind the tables");
     {   // no occurrences yet
         uint4* const t4 = reinterpret_cast<uint4*>(Hc.table);
         t4[tid] = uint4{0u, 0u, 0u, 0u}; t4[tid + kTile] = uint4{0u, 0u, 0u, 0u};
     }
     for (u32 t = tFrom; t < tTo; ++t) {
         const u32 tileStart = t * kTilePos;
+        u16* const tilePred = Hc.links + (tileStart & (kHcRing * kTilePos - 1));
         const u32 q0 = 4 * tid, p0 = tileStart + q0;
         const u32* const d32 = reinterpret_cast<const u32*>(L.in) + (p0 >> 2);
         const u32 dm1 = p0 ? d32[-1] : 0u, d0 = d32[0], d1 = d32[1], d2 = d32[2], d3 = d32[3], d4 = d32[4];
@@ -379,7 +377,7 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
                 valid[j] = p + 8 <= n && p >= lowLimit;
                 h4 |= (u64)(valid[j] ? hidx(hash_shortp<5>(a1[j])) : 0xFFFFu) << (16 * j);
             }
-            *reinterpret_cast<u64*>(&Hc.hashes[q0]) = h4;
+            *reinterpret_cast<u64*>(&hashes[q0]) = h4;
         }
         ZMI_DSTAMP(16);
         lds_barrier();
@@ -388,7 +386,7 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
         if (wave == 0) {                                   // eight groups per step, the next step's hashes already on their way
             u32 hn[8];
 #pragma unroll
-            for (u32 k = 0; k < 8; ++k) hn[k] = Hc.hashes[k * 64 + lane];
+            for (u32 k = 0; k < 8; ++k) hn[k] = hashes[k * 64 + lane];
 #pragma unroll 1
             for (u32 g = 0; g < 64; g += 8) {
                 u32 h[8], pv[8];
@@ -396,7 +394,7 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
                 for (u32 k = 0; k < 8; ++k) h[k] = hn[k];
                 if (g + 8 < 64) {
 #pragma unroll
-                    for (u32 k = 0; k < 8; ++k) hn[k] = Hc.hashes[(g + 8 + k) * 64 + lane];
+                    for (u32 k = 0; k < 8; ++k) hn[k] = hashes[(g + 8 + k) * 64 + lane];
                 }
                 u32 hx[8], val[8];                         // (branch-free: a position that is not linked adds 0 to bucket 0)
 #pragma unroll
@@ -443,10 +441,13 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             // flight instead of one, both leave the time where it is; an attempt costs 1.0 - 1.7 ms per GiB).
             // Positions 0 and 2 of a thread are walked side by side, then 1 and 3 (which may take their left neighbour's
             // continuation): two chains in flight per lane hide each other's LDS latency.
+            // (one LDS read whatever the tile — an index, not a choice between arrays: a pointer chosen among LDS and global memory
+            //  makes the load a flat one, which waits for both memories; only positions further back take the branch to L2)
+            const u32 ringLow = tileStart >= (kHcRing - 1) * kTilePos ? tileStart - (kHcRing - 1) * kTilePos : 0u;
             auto link = [&](u32 cpos) -> u32 {
-                return cpos >= tileStart ? (u32)tilePred[cpos - tileStart]
-                     : cpos + kRing * kTilePos >= tileStart ? (u32)ring[((cpos >> kTileLog) % kRing) * kTilePos + (cpos & (kTilePos - 1))]
-                     : (u32)chainG[cpos];
+                u32 nx = Hc.links[cpos & (kHcRing * kTilePos - 1)];
+                if (cpos < ringLow) nx = chainG[cpos];
+                return nx;
             };
             auto measure = [&](auto J, u32 cpos, u32& pw) {           // the candidate passed the filter: its full length, up to 64
                 constexpr u32 j = decltype(J)::value;
@@ -493,11 +494,9 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             if (p0 < n) *reinterpret_cast<u64*>(candG + p0) = out4;
         }
         ZMI_DSTAMP(20);
-        lds_barrier();                                     // (the search is done with the ring slot this tile takes over)
-        ZMI_DSTAMP(21);
-        if (tid < 512) reinterpret_cast<uint4*>(ring + (t % kRing) * kTilePos)[tid] = reinterpret_cast<const uint4*>(tilePred)[tid];
-        // the links in global memory are read by tiles at least kRing + 1 after this one: every kRing-th tile waits for the stores
-        if (t % kRing == kRing - 1) __syncthreads(); else lds_barrier();
+        // (the search is done with the hashes and with the ring slot the next tile takes over)
+        // the links in global memory are read by tiles at least kHcRing after this one: every kHcRing-th tile waits for the stores
+        if (t % kHcRing == kHcRing - 1) __syncthreads(); else lds_barrier();
         ZMI_DSTAMP(22);
     }
 }
@@ -524,6 +523,9 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
     return;
 #endif
     // ---------------- I: candidates of every position, tile by tile ----------------
+#if defined(ZMI_EXP_STOP) && ZMI_EXP_STOP == 3
+    if constexpr (MODE == 2) { hc_tiles(L, n, lowLimit >> kTileLog, hist >> kTileLog, fromTile, lowLimit, hcDepth, candG, chainG, tid, lane, wave); __syncthreads(); return; }
+#endif
     if constexpr (MODE == 2) hc_tiles(L, n, lowLimit >> kTileLog, nTiles, fromTile, lowLimit, hcDepth, candG, chainG, tid, lane, wave
 #ifdef ZMI_LZ_STAMPS
                                       , dAcc, dLast
