@@ -444,10 +444,14 @@ __device__ __forceinline__ void hc_tiles(LzLds& L, const u32 n, const u32 tFrom,
             // (one LDS read whatever the tile — an index, not a choice between arrays: a pointer chosen among LDS and global memory
             //  makes the load a flat one, which waits for both memories; only positions further back take the branch to L2)
             const u32 ringLow = tileStart >= (kHcRing - 1) * kTilePos ? tileStart - (kHcRing - 1) * kTilePos : 0u;
+            //  (the pointers carry their address spaces: left generic, the compiler turns the branch into a choice of pointer again)
+            const __attribute__((address_space(3))) u16* const linksL = (const __attribute__((address_space(3))) u16*)Hc.links;
+            const __attribute__((address_space(1))) u16* const linksG = (const __attribute__((address_space(1))) u16*)chainG;
             auto link = [&](u32 cpos) -> u32 {
-                u32 nx = Hc.links[cpos & (kHcRing * kTilePos - 1)];
-                if (cpos < ringLow) nx = chainG[cpos];
-                return nx;
+                const u32 near = linksL[cpos & (kHcRing * kTilePos - 1)];
+                u32 far = 0;                               // (registers of their own: neither load waits for the other)
+                if (cpos < ringLow) far = linksG[cpos];
+                return cpos < ringLow ? far : near;
             };
             auto measure = [&](auto J, u32 cpos, u32& pw) {           // the candidate passed the filter: its full length, up to 64
                 constexpr u32 j = decltype(J)::value;
