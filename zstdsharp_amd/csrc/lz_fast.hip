@@ -1016,11 +1016,15 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
     u32 regionCursor = 0;                // != 0: the chunk goes on in lz_region_kernel (parse cursor + 1)
     u32 prevDensity = 0xFFFFFFFFu;       // matches per 4096 positions in the previous tile (scaled by its stride)
     u32 prevStride = 0;                  // the previous iteration's stride
-    u64* const superCov = reinterpret_cast<u64*>(L.jump);      // 256 coverage words of a super-tile (L.jump is idle outside dense tiles)
+    u64* const superCov = reinterpret_cast<u64*>(L.jump);      // up to 1024 coverage words of a super-tile (L.jump is idle outside dense tiles)
     // history / dictionary tiles (those wholly below lowLimit are padding) only fill the tables: searched, never parsed
     if (DICT && lowLimit < hist) insert_tiles<MODE>(L, n, lowLimit >> kTileLog, hist >> kTileLog, 0xFFFFFFFFu, lowLimit, nullptr, tid);
     ZMI_STAMP(8);                        // (dense-tile select shares the slot: told apart by the workload)
+#ifdef ZMI_EXP_LZSTOP
+    for (u32 t = hist >> kTileLog, it = 0; t < nTiles && it < ZMI_EXP_LZSTOP - 1; ++it) {      // (ablation build: the first N - 1 iterations only)
+#else
     for (u32 t = hist >> kTileLog, it = 0; t < nTiles; ++it) {
+#endif
         const u32 tileStart = t * kTilePos;
         // stride: every 2nd / 4th position after a sparse tile; where a strided iteration found next to nothing either, every
         // 8th, then every 16th (the reference's step keeps growing the same way while nothing matches, U/ZstdFast.cs:130-136)
@@ -1032,9 +1036,12 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
         // Super-tile: where only every 2nd / 4th (8th, 16th) position is probed, TWO / FOUR tiles (as many as are left in
         // full) are taken in one iteration — up to 4096 probes, four per thread as in a dense tile, so their LDS latencies
         // overlap and the two barriers are paid once per 8 / 16 KiB.  The tile arrays are then indexed by probe slot
-        // (slot order = position order), coverage has up to 256 words, and the selection is the serial walk of wave 0
+        // (slot order = position order), coverage has up to 1024 words, and the selection is the serial walk of wave 0
         // whatever the number of matches (capped; what is left out stays literals).
-        u32 nSubT = strideSel > 2 ? 4u : 1u << strideSel;          // at most 16 KiB per iteration: the stride adapts again after that
+        // 4096 probes per iteration whatever the stride, up to the rest of the chunk at 16: an iteration costs its three barriers
+        // (3.3 us; 0.2 ms per GiB) far more than its probes — measured against at most 16 KiB per iteration (the stride adapting
+        // again after that): Zipf bytes 1.37 -> 1.15 ms per GiB, random bytes 1.07 -> 0.86, the mixed corpus 1.71 -> 1.60, same sizes
+        u32 nSubT = 1u << strideSel;
         { const u32 fullLeft = (n - tileStart) >> kTileLog; if (nSubT > fullLeft) nSubT = fullLeft; }
         const bool super = nSubT >= 2;                                                  // uniform
         if (!super) { nSubT = 1; if (strideSel > 2) strideSel = 2; }                    // (a lone tile knows strides 1, 2, 4 only)
