@@ -10,6 +10,7 @@ BENCH_ARGS="" bash tools/profile_round.sh ${R}_zipf
 BENCH_ARGS="--input text" bash tools/profile_round.sh ${R}_text
 BENCH_ARGS="--input text --size-mib 10 --steps 20" bash tools/profile_round.sh ${R}_text10
 BENCH_ARGS="--input mixed --level 5" bash tools/profile_round.sh ${R}_mixed5
+BENCH_ARGS="--mode decompress --input mixed --level 5 --frame-mib 1 --size-mib 1024 --unique-mib 256" bash tools/profile_round.sh ${R}_dec5g1
 BENCH_ARGS="--mode decompress --input mixed --level 5 --frame-mib 1 --size-mib 4096 --unique-mib 256" bash tools/profile_round.sh ${R}_dec5
 BENCH_ARGS="--mode decompress --input mixed --level 5 --frame-mib 256 --size-mib 256 --unique-mib 256" bash tools/profile_round.sh ${R}_dec5one
 ls "$ROOT/gpurun_out/prof"

@@ -751,7 +751,8 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
             const u32 off = C[pos], len = C[pos + 1], plen = C[prev + 1];
             const u32 pe = k ? lo + prev + plen : cursor;
             Seq sq; sq.offBase = off + 3; sq.litLength = (u16)(lo + pos - pe); sq.mlBase = (u16)(len - 3);
-            seqOut[nbSeq + k] = sq;
+            // (streaming stores, here and for the literals: what this kernel should keep in L2 is its candidate plane)
+            __builtin_nontemporal_store((u64)sq.offBase | ((u64)sq.litLength << 32) | ((u64)sq.mlBase << 48), reinterpret_cast<u64*>(seqOut + nbSeq + k));
         }
         lds_barrier();
         // ---- literals: compacted in LDS first (the candidates' place: they are spent), then written out in whole 16-byte pieces:
@@ -790,7 +791,8 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
             for (u32 i = tid; i < body; i += kTile) {
                 uint4 v; const u8* sp = S + head + 16 * i;
                 v.x = *(const u32u*)sp; v.y = *(const u32u*)(sp + 4); v.z = *(const u32u*)(sp + 8); v.w = *(const u32u*)(sp + 12);
-                *reinterpret_cast<uint4*>(dst + head + 16 * i) = v;
+                typedef u32 __attribute__((ext_vector_type(4))) v4u;
+                __builtin_nontemporal_store(v4u{v.x, v.y, v.z, v.w}, reinterpret_cast<v4u*>(dst + head + 16 * i));
             }
             const u32 done = head + (body << 4);
             if (tid < totK - done) dst[done + tid] = S[done + tid];
@@ -1566,12 +1568,17 @@ __global__ __launch_bounds__(1024) void lz_region_kernel(const u8* __restrict__ 
         const u8* __restrict__ from = onePiece ? in - prefixLen : in;
         const u32 at = onePiece ? lowLimit : hist, bytes = onePiece ? prefixLen + nData : nData;
         if ((((uintptr_t)from) | at) % 16 == 0) {
-            const uint4* in4 = reinterpret_cast<const uint4*>(from);
             uint4* l4 = reinterpret_cast<uint4*>(L.in + at);
             const u32 full = bytes >> 4;
             uint4 v0, v1, v2, v3;
             const u32 i0 = tid, i1 = tid + kTile, i2 = tid + 2 * kTile, i3 = tid + 3 * kTile;
-            v0 = in4[i0 < full ? i0 : 0]; v1 = in4[i1 < full ? i1 : 0]; v2 = in4[i2 < full ? i2 : 0]; v3 = in4[i3 < full ? i3 : 0];
+            {   // (streaming loads: see the stores of dense_rest)
+                typedef u32 __attribute__((ext_vector_type(4))) v4u;
+                const v4u* n4 = reinterpret_cast<const v4u*>(from);
+                const v4u a0 = __builtin_nontemporal_load(n4 + (i0 < full ? i0 : 0)), a1 = __builtin_nontemporal_load(n4 + (i1 < full ? i1 : 0));
+                const v4u a2 = __builtin_nontemporal_load(n4 + (i2 < full ? i2 : 0)), a3 = __builtin_nontemporal_load(n4 + (i3 < full ? i3 : 0));
+                v0 = uint4{a0.x, a0.y, a0.z, a0.w}; v1 = uint4{a1.x, a1.y, a1.z, a1.w}; v2 = uint4{a2.x, a2.y, a2.z, a2.w}; v3 = uint4{a3.x, a3.y, a3.z, a3.w};
+            }
             if (i0 < full) l4[i0] = v0;
             if (i1 < full) l4[i1] = v1;
             if (i2 < full) l4[i2] = v2;
