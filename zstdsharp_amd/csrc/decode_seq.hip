@@ -740,6 +740,9 @@ __global__ __launch_bounds__(64 * W) void exec_matches_wide_kernel(const u8* __r
             }
             bool mine = hasMatch;
             const bool longM = mlR > 64;
+#if defined(ZMI_EXP_EXEC) && ZMI_EXP_EXEC == 1
+            continue;                                            // (ablation build: no rounds, no copies)
+#endif
             for (u32 round = 0; ; ++round) {
                 const u64* const D = doneBits[round & 1];
                 u64 all = ~0ull, own = 0;
@@ -755,8 +758,12 @@ __global__ __launch_bounds__(64 * W) void exec_matches_wide_kernel(const u8* __r
                         if (bits & ~D[w]) { ready = false; break; }
                     }
                 }
+#if defined(ZMI_EXP_EXEC) && ZMI_EXP_EXEC == 2
+                u64 lm = 0;                                      // (ablation build: the rounds without their copies)
+#else
                 if (ready && !longM) lane_match_copy(o + dMatchR, off, mlR);
                 u64 lm = ballot(ready && longM);
+#endif
                 while (lm) {
                     const u32 i = ctz64(lm); lm &= lm - 1;
                     wave_match_copy(o + read_lane(dMatchR, i), read_lane(off, i), read_lane(mlR, i), lane);
