@@ -1093,7 +1093,9 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
         }
         ZMI_STAMP(1);
-        if (!fused) __syncthreads();           // every probe of this tile precedes every insert of this tile
+        // (LDS-only barriers in this loop: __syncthreads() also waits for the wave's outstanding global loads — the NEXT chunk's
+        //  bytes, fetched on purpose behind this chunk's work — and for every sequence and literal store to be acknowledged)
+        if (!fused) lds_barrier();             // every probe of this tile precedes every insert of this tile
         ZMI_STAMP(2);
         u64 mmJ[kPPT], cmJ[kPPT];
         const bool slotMasks = strideLog == 0 || super;      // (uniform) array index = j * kTile + tid: a wave's ballots ARE its mask words
@@ -1227,7 +1229,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
         }
         ZMI_STAMP(3);
-        __syncthreads();
+        lds_barrier();
         ZMI_STAMP(4);
         const u32 c0 = cursor > tileStart ? cursor - tileStart : 0;       // entry cursor, tile-relative
         const u32 matchCount = L.matchCount[par];
@@ -1290,7 +1292,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 }
             }
             ZMI_STAMP(8);
-            __syncthreads();
+            lds_barrier();
             ZMI_STAMP(8);
             if (wave >= w0) {                                                 // (uniform) earlier waves lie before the cursor: nothing selected
                 u32 ent = e0, kStart = k0;
@@ -1315,7 +1317,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 }
             }
             ZMI_STAMP(8);
-            __syncthreads();
+            lds_barrier();
             ZMI_STAMP(8);
             if (wave == 0) {
                 // ---- finish capped matches in order; drop the selections they swallow ----
@@ -1350,7 +1352,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                 if (lane == 63) L.wordRank[64] = incl;
                 if (lane == 0) endOf[0] = cursor;
             }
-            __syncthreads();
+            lds_barrier();
             ZMI_STAMP(9);
             // every selected match files its position and its end under its rank; after the barrier the matches are emitted BY RANK,
             // one per lane from lane 0 up (a tile selects a few hundred of its 4096 positions: emitting by position would run the
@@ -1366,7 +1368,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
                     selPos[rank] = (u16)q;
                 }
             }
-            __syncthreads();
+            lds_barrier();
             {
                 const u32 nSelT = L.wordRank[64];
                 if (tid < nSelT) { const u32 q = selPos[tid]; emit_match(tileStart, q, q, tid, endOf[tid + 1]); }
@@ -1422,7 +1424,7 @@ __global__ __launch_bounds__(1024) void lz_kernel(const u8* __restrict__ src, u6
             }
         }
         ZMI_STAMP(5);
-        if (any) __syncthreads();              // (uniform) a tile without a selection has nothing to hand over
+        if (any) lds_barrier();                // (uniform) a tile without a selection has nothing to hand over
         ZMI_STAMP(6);
         const u32 nSel = any ? L.wordRank[64] : 0u;
         // ---------------- literals of this tile: not covered by a selected match, not behind the entry cursor ----------------
