@@ -180,9 +180,6 @@ __device__ __forceinline__ u32 match_len_far(const LzLds& L, u32 p, const u8* __
     return l >= 4 ? l : 0;
 }
 
-// workgroup barrier that orders LDS only: __syncthreads() also waits until every global store of the wave has been acknowledged
-// (vmcnt), which the region parse does not need where it only writes results out
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Region parse (fast strategy, dense data).  The tile loop above computes a verified match at EVERY position and then selects

@@ -31,6 +31,9 @@ __device__ __forceinline__ u32 wave_scan_incl(u32 v)
     return v;
 }
 // make one wave's LDS writes visible to its other lanes (single-wave workgroups need no s_barrier)
+// workgroup barrier that orders LDS only: __syncthreads() also waits until every global store of the wave has been acknowledged
+// (vmcnt), which the region parse does not need where it only writes results out
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ void wave_lds_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ u32 wave_sum(u32 v)
 {
