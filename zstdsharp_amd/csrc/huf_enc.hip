@@ -53,10 +53,7 @@ struct HufTreeLds {
 };
 
 struct HufBuildLds {
-#ifndef ZMI_HIST_COPIES
-#define ZMI_HIST_COPIES 2
-#endif
-    u32 hist[4][ZMI_HIST_COPIES][256];
+    u32 hist[4][2][256];         // two copies per wave (more copies cost more in residency than they save in same-address atomics: DESIGN 5)
     u32 sample[2][256];
     u32 count[256];
     Node nodes[513];
@@ -339,14 +336,14 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
     // ZSTD_compressLiterals: <= 63 literals are stored raw (no previous table in a one-block frame)
     // (rawLiterals: literal compression is off — the fast strategy with a step, i.e. negative levels; U/ZstdCompressInternal.cs:146-173)
     if (litSize <= 63 || rawLiterals) return;  // huf_tree_kernel stores them raw
-    for (u32 i = tid; i < 4 * ZMI_HIST_COPIES * 256; i += 256) (&L.hist[0][0][0])[i] = 0;
+    for (u32 i = tid; i < 8 * 256; i += 256) (&L.hist[0][0][0])[i] = 0;
     for (u32 i = tid; i < 2 * 256; i += 256) (&L.sample[0][0])[i] = 0;
     for (u32 i = tid; i < 513; i += 256) { Node z; z.count = 0; z.parent = 0; z.byte = 0; z.nbBits = 0; L.nodes[i] = z; }
     __syncthreads();
     const u32 seg = (litSize + 3) / 4;
     {   // wave w counts segment w (these are also the per-stream histograms that size the four streams)
         const u32 s0 = wave * seg, s1 = (s0 + seg < litSize) ? s0 + seg : litSize;
-        u32* H = L.hist[wave][lane & (ZMI_HIST_COPIES - 1)];      // copies per wave, by lane: divides same-address atomic serialisation
+        u32* H = L.hist[wave][lane & 1];      // two copies per wave, by lane parity: halves same-address atomic serialisation
         if (s0 < s1) {
             // 16 bytes per lane per load (aligned: the literal buffer is, a caller's source need not be): a byte-per-lane loop is
             // bound by one global-load latency per 64 bytes
@@ -412,7 +409,7 @@ __global__ __launch_bounds__(256) void huf_hist_kernel(const u8* __restrict__ li
     {
         u32 tot = 0;
 #pragma unroll
-        for (u32 w = 0; w < 4; ++w) { u32 v = 0; for (u32 cp = 0; cp < ZMI_HIST_COPIES; ++cp) v += L.hist[w][cp][tid]; W->hist[w][tid] = (u16)v; tot += v; }
+        for (u32 w = 0; w < 4; ++w) { const u32 v = L.hist[w][0][tid] + L.hist[w][1][tid]; W->hist[w][tid] = (u16)v; tot += v; }
         L.count[tid] = tot;
     }
     if (doSample && wave < 2) {

@@ -520,7 +520,7 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
 #ifdef ZMI_LZ_STAMPS
     unsigned long long dLast = __builtin_amdgcn_s_memtime(); unsigned long long dAcc[14] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-#if defined(ZMI_EXP_STOP) && ZMI_EXP_STOP == 1
+#if defined(ZMI_EXP_STOP) && ZMI_EXP_STOP == 1       // ablation builds (diagnostic, make variant DEFS=-DZMI_EXP_STOP=n): stop after a phase
     return;
 #endif
     // ---------------- I: candidates of every position, tile by tile ----------------
@@ -551,19 +551,6 @@ __device__ __forceinline__ void dense_rest(LzLds& L, const u32 n, const u32 inse
     for (u32 lo = fromTile * kTilePos; lo < n; lo += kPassPos) {
         const u32 hi = lo + kPassPos < n ? lo + kPassPos : n;
         const u32 nReg = (hi - lo + 63) >> 6;
-#ifdef ZMI_EXP_LOAD2
-        for (u32 rep = 0; rep < ZMI_EXP_LOAD2; ++rep) {
-            const u32 cnt = hi - lo + 64;
-            uint4 v[4];
-            asm volatile("" ::: "memory");
-#pragma unroll
-            for (u32 k = 0; k < 4; ++k) { const u32 i = (tid + k * kTile) * 8; v[k] = *reinterpret_cast<const uint4*>(candG + lo + (i < cnt ? i : 0)); }
-#pragma unroll
-            for (u32 k = 0; k < 4; ++k) { const u32 i = (tid + k * kTile) * 8; if (i < cnt) *reinterpret_cast<uint4*>(C + i) = v[k]; }
-            lds_barrier();
-            asm volatile("" ::: "memory");
-        }
-#endif
         {   // candidates of the pass (+ one region: a lane's stretch may reach that far): global (L2) -> LDS, 16 bytes per lane,
             // the four loads of a thread in flight together
             const u32 cnt = hi - lo + 64;
