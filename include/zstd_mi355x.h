@@ -161,6 +161,9 @@ size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* dctx, unsigned mode);
 /* waves per frame in the match-execution stage: 0 = by the number of frames in the call (default: few frames get up to 16 waves
  * each — a batch of 64 x waves sequences per round of dependent copies —, more than 2048 frames one wave each), else 1, 2, 4, 8 or 16 */
 size_t ZSTDMI_DCtx_setExecWaves(ZSTD_DCtx* dctx, unsigned waves);
+/* diagnostic: 1 if the last decompress call listed its frames with the exact serial walk (frames naming a dictionary, frames
+ * without a content size, damaged input) instead of the parallel one, 0 if not, -1 without a context */
+int ZSTDMI_debugLastWalkSerial(const ZSTD_DCtx* dctx);
 
 /* same contracts as ZSTD_compress2 / ZSTD_decompressDCtx, but src and dst MUST be device pointers (no staging) */
 size_t ZSTDMI_compressDevice(ZSTD_CCtx* cctx, void* d_dst, size_t dstCapacity, const void* d_src, size_t srcSize);

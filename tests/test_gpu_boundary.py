@@ -256,3 +256,31 @@ def test_redundancy_at_a_distance_keeps_the_levels_history(gpu_lib, oracle):
     print(f"distance-only redundancy: level 5 {len(auto) / len(data):.4f}, history forced {len(forced) / len(data):.4f}, level 1 {len(l1) / len(data):.4f}")
     assert auto == forced, "the level's own path (history in multi-block frames), not the sparse-input fallback"
     assert auto != l1 and len(auto) <= len(l1) * 1.001, (len(auto), len(l1))
+
+
+def test_frame_magics_inside_the_payload_do_not_derail_the_parallel_walk(gpu_lib, oracle):
+    """The decoder lists a call's frames in parallel (ZSTD_findFrameSizeInfo per 128 KiB segment of the input, U/ZstdDecompress.cs:
+    654-760, linked afterwards) and keeps the exact serial walk for what that cannot settle.  Incompressible payload is stored
+    verbatim, so it may hold the bytes of a frame header: here a skippable-frame header (U/ZstdDecompress.cs:553-575) whose size
+    field reaches far outside its segment — "valid" as far as one segment can tell — every 1000 bytes.  A chain that does not land on
+    a frame is not a frame: the call must still take the parallel walk (the serial one costs 2.4 us a frame), and decode exactly."""
+    import numpy as np
+    rng = np.random.default_rng(5)
+    n = 6 << 20
+    data = bytearray(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    for k, off in enumerate(range(16, n - 16, 1000)):
+        magic = 0x184D2A50 + (k & 15)
+        skip = 150000 + 7919 * (k % 97)                              # out of the segment, inside the input
+        data[off:off + 8] = magic.to_bytes(4, "little") + skip.to_bytes(4, "little")
+    data = bytes(data)
+    with z.Compressor(1) as c, z.Decompressor() as d:
+        comp = c.Wrap(data)
+        assert (0x184D2A53).to_bytes(4, "little") in comp, "the payload is stored verbatim"
+        assert d.Unwrap(comp) == data
+        assert gpu_lib.ZSTDMI_debugLastWalkSerial(d.dctx) == 0, "the parallel walk"
+        assert oracle.decompress(comp, n) == data
+        # ... and what the serial walk is for still gets it: a frame without a content size
+        c.SetParameter(200, 0)
+        unsized = c.Wrap(data[:300000])
+        assert d.Unwrap(unsized) == data[:300000]
+        assert gpu_lib.ZSTDMI_debugLastWalkSerial(d.dctx) == 1

@@ -63,6 +63,7 @@ SIGNATURES = {
     "ZSTDMI_DCtx_setLongFrames": (c_size_t, [c_void_p, c_uint]),
     "ZSTDMI_DCtx_setOverlap": (c_size_t, [c_void_p, c_uint]),
     "ZSTDMI_DCtx_setExecWaves": (c_size_t, [c_void_p, c_uint]),
+    "ZSTDMI_debugLastWalkSerial": (c_int, [c_void_p]),
     "ZSTDMI_CCtx_setParser": (c_size_t, [c_void_p, c_uint]),
     "ZSTDMI_compressDevice": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "ZSTDMI_decompressDevice": (c_size_t, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),

@@ -151,6 +151,16 @@ __global__ __launch_bounds__(64) void walk_segments_kernel(const u8* __restrict_
             if (st == 0) { count++; dstBytes += o.content; nBlocks += o.nbBlocks; }
             pos = o.next;
         }
+        // A magic that turns up by chance inside a frame's payload (the sixteen skippable-frame magics: once per 270 MB of
+        // incompressible payload) can chain out of the segment too — a skippable frame of any size that stays inside the input is
+        // "valid" — and, where it lies in front of the segment's first real frame, the link check then sends the whole call to the
+        // serial walk (40 ms for 16 384 frames).  A real chain leaves the segment AT a frame (or at the end of the input): a
+        // candidate whose chain lands anywhere else is not one.
+        if (ok && pos != srcSize) {
+            u32 v = 0;
+            if (srcSize - pos >= 4) v = readLE32(src + pos);
+            if (!(v == 0xFD2FB528u || (v & 0xFFFFFFF0u) == 0x184D2A50u)) ok = false;
+        }
         if (ok && nBlocks < 0xFFFFFFF0ull) { r.entry = cand; r.exit = pos; r.dstBytes = dstBytes; r.count = count; r.blocks = (u32)nBlocks; r.valid = 1; break; }
         scan = cand + 1;           // false positive (or a corrupt stream: the link check then sends us to the serial walk)
     }

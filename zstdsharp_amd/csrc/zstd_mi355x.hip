@@ -181,6 +181,7 @@ struct ZSTD_DCtx_s {
     hipStream_t ownStream = nullptr, stream = nullptr;
     hipStream_t aux = nullptr; hipEvent_t auxDone = nullptr;     // the literal decoder beside seq_decode (decompress_device)
     int overlapMode = 0;        // ZSTDMI_DCtx_setOverlap: 0 = by block count, 1 = never, 2 = always
+    bool lastWalkSerial = false; // the last call's frames were listed by the serial walk (ZSTDMI_debugLastWalkSerial)
     int execWaves = 0;          // ZSTDMI_DCtx_setExecWaves: waves per frame in exec_matches, 0 = by the number of frames
     DevBuf frames, blocks, recs, status, scratch, walkWs, slowFlags, stageSrc, stageDst, origin, originList;
     int originMode = 0;         // ZSTDMI_DCtx_setLongFrames: 0 = by cost (see decompress_device), 1 = never, 2 = every frame of 1 MiB or more
@@ -1008,6 +1009,7 @@ static size_t decompress_device(ZSTD_DCtx* d, u8* d_dst, size_t dstCapacity, con
     launch_frame_walk_count(d_src, srcSize, maxFrames, status, (u8*)d->walkWs.p, s);
     if (!read_status(st)) return ZERR(kErrGeneric);
     const bool serialWalk = !st[kStUsable];
+    d->lastWalkSerial = serialWalk;
     if (serialWalk) {   // the segment links did not close: take the exact serial walk (it also yields the reference's error code)
         launch_frame_walk_serial(d_src, srcSize, nullptr, nullptr, maxFrames, status, dictID, 0, s);
         if (!read_status(st)) return ZERR(kErrGeneric);
@@ -1507,6 +1509,7 @@ size_t ZSTDMI_DCtx_setDevices(ZSTD_DCtx* d, const int* devices, int n)
 }
 size_t ZSTDMI_CCtx_setStream(ZSTD_CCtx* c, void* st) { size_t e = cctx_bind(c); if (isErr(e)) return e; c->stream = st ? (hipStream_t)st : c->ownStream; return 0; }
 size_t ZSTDMI_DCtx_setStream(ZSTD_DCtx* d, void* st) { size_t e = dctx_bind(d); if (isErr(e)) return e; d->stream = st ? (hipStream_t)st : d->ownStream; return 0; }
+int ZSTDMI_debugLastWalkSerial(const ZSTD_DCtx* d) { return d ? (int)d->lastWalkSerial : -1; }
 size_t ZSTDMI_DCtx_setExecWaves(ZSTD_DCtx* d, unsigned waves) { if (!d || (waves != 0 && waves != 1 && waves != 2 && waves != 4 && waves != 8 && waves != 16)) return ZERR(kErrParameterOutOfBound); d->execWaves = (int)waves; return 0; }
 size_t ZSTDMI_DCtx_setOverlap(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->overlapMode = (int)mode; return 0; }
 size_t ZSTDMI_DCtx_setLongFrames(ZSTD_DCtx* d, unsigned mode) { if (!d || mode > 2) return ZERR(kErrParameterOutOfBound); d->originMode = (int)mode; return 0; }
